@@ -1,0 +1,136 @@
+"""SOAP-mode golden vectors, produced by the reference's closed `soap` / `2bwt-builder`
+ELFs (Classify/Runsoap/soap2.21release).  Called from oracle/gen_goldens.py.
+
+Reference data used: a 48-sequence subset of validation_dataset/rdp_download_373seqs.fa
+(the validation set the reference ships; it carries IUPAC codes and near-duplicate 16S
+sequences, which is what makes multi-hit and ambiguity behaviour observable).  Reads are
+synthetic (seeded), planted with 0..3 substitutions on either strand, plus edge cases:
+lengths 20..400, N runs, sequence ends, lower case, IUPAC read characters.
+
+Outputs (tests/golden/soap/): ref.fa, reads.fa, out_r2.txt (-M 4 -r 2), out_r1.txt (-M 4 -r 1),
+unmapped_r2.txt (-u).  The ~660 MB index files stay in the scratch directory.
+"""
+import os
+import random
+import shutil
+import subprocess
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def rc(s):
+    return "".join(COMP.get(c, "N") for c in reversed(s))
+
+
+def read_fasta(p):
+    seqs, name, buf = [], None, []
+    for l in open(p):
+        l = l.rstrip("\n")
+        if l.startswith(">"):
+            if name is not None:
+                seqs.append((name, "".join(buf)))
+            name, buf = l[1:], []
+        else:
+            buf.append(l)
+    seqs.append((name, "".join(buf)))
+    return seqs
+
+
+def other(b, rng):
+    return rng.choice([x for x in "ACGT" if x != b])
+
+
+def mutate(s, positions, rng):
+    x = list(s)
+    for p in positions:
+        x[p] = other(x[p], rng)
+    return "".join(x)
+
+
+def generate(scratch, gold, soap_dir, ref_root="/root/reference"):
+    out = os.path.join(gold, "soap")
+    os.makedirs(out, exist_ok=True)
+    rng = random.Random(20261003)
+    allseq = read_fasta(os.path.join(ref_root, "validation_dataset", "rdp_download_373seqs.fa"))
+    byid = {n.split()[0]: i for i, (n, _) in enumerate(allseq)}
+    want = ["S000469148", "S000414323", "S000469450", "S000385166", "S000414322", "S000384778", "S000433096",
+            "S000436258", "S000388840", "S000870881"]
+    idx = [byid[w] for w in want]
+    for i in range(len(allseq)):
+        if len(idx) >= 48:
+            break
+        if i not in idx:
+            idx.append(i)
+    idx.sort()
+    ref = [allseq[i] for i in idx]
+    work = os.path.join(scratch, "soap")
+    os.makedirs(work, exist_ok=True)
+    with open(os.path.join(work, "ref.fa"), "w") as f:
+        for n, s in ref:
+            f.write(">" + n + "\n")
+            for k in range(0, len(s), 80):
+                f.write(s[k:k + 80] + "\n")
+    # what the aligner sees: upper case, every non-ACGT letter read as G (observed)
+    clean = [(n.split()[0], "".join(c if c in "ACGT" else "G" for c in s.upper())) for n, s in ref]
+
+    reads = []
+    for r in range(320):
+        si = rng.randrange(len(clean))
+        name, s = clean[si]
+        L = 150
+        off = rng.randrange(0, len(s) - L)
+        w = s[off:off + L]
+        k = rng.choice([0, 0, 1, 1, 2, 2, 2, 3])
+        w = mutate(w, rng.sample(range(L), k), rng)
+        strand = rng.choice("+-")
+        reads.append((f"r{r}_{name}_{off + 1}_{strand}_{k}", w if strand == "+" else rc(w)))
+    name, s = clean[9]
+    for L in (20, 26, 27, 30, 40, 47, 48, 60, 100, 149, 151, 200, 255, 256, 257, 300, 400):
+        w = s[200:200 + L]
+        reads.append((f"len{L}", w))
+        reads.append((f"len{L}_mm2", mutate(w, [3, L - 4], rng)))
+        reads.append((f"len{L}_mm2_rc", rc(mutate(w, [3, L - 4], rng))))
+    w = s[300:450]
+    gpos = [i for i, c in enumerate(w) if c == "G"]
+    for k in (1, 2, 4, 5, 6, 7):
+        x = list(w)
+        for p in gpos[:k]:
+            x[p] = "N"
+        reads.append((f"N_on_G_{k}", "".join(x)))
+    reads.append(("N_mm_50", w[:50] + "N" + w[51:]))
+    reads.append(("N_mm_50_100", w[:50] + "N" + w[51:100] + "N" + w[101:]))
+    reads.append(("N_mm_rc", rc(w[:50] + "N" + w[51:])))
+    reads.append(("iupac_read", w[:60] + "R" + w[61:90] + "y" + w[91:]))
+    reads.append(("lower_case", w.lower()))
+    reads.append(("name with blanks", w))
+    for o in (0, 1, 136, 137, 148, 149):
+        m = mutate(w, [o], rng)
+        reads.append((f"plus_o{o}", m))
+        reads.append((f"minus_o{o}", rc(m)))
+    for a, b in ((0, 1), (0, 140), (5, 60), (80, 145), (100, 136), (100, 137), (140, 145), (74, 75)):
+        m = mutate(w, [a, b], rng)
+        reads.append((f"plus_{a}_{b}", m))
+        reads.append((f"minus_{a}_{b}", rc(m)))
+    for k in (0, 1, 2):
+        reads.append((f"end_minus{k}", s[len(s) - 150 - k:len(s) - k]))
+        reads.append((f"end_minus{k}_rc", rc(s[len(s) - 150 - k:len(s) - k])))
+    reads.append(("seq_start", s[:150]))
+    reads.append(("seq_start_rc", rc(s[:150])))
+    reads.append(("span_two_seqs", clean[9][1][-75:] + clean[10][1][:75]))
+    reads.append(("random_read", "".join(rng.choice("ACGT") for _ in range(150))))
+    with open(os.path.join(work, "reads.fa"), "w") as f:
+        for n, s_ in reads:
+            f.write(f">{n}\n{s_}\n")
+
+    builder = os.path.join(soap_dir, "2bwt-builder")
+    soap = os.path.join(soap_dir, "soap")
+    subprocess.run([builder, "ref.fa"], cwd=work, check=True, timeout=600, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    for r, tag in (("2", "r2"), ("1", "r1")):
+        subprocess.run([soap, "-a", "reads.fa", "-D", "ref.fa.index", "-o", f"out_{tag}.txt", "-u",
+                        f"unmapped_{tag}.txt", "-p", "1", "-M", "4", "-r", r], cwd=work, check=True, timeout=600,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for n in ("ref.fa", "reads.fa", "out_r2.txt", "out_r1.txt", "unmapped_r2.txt"):
+        shutil.copy(os.path.join(work, n), os.path.join(out, n))
+    rows = sum(1 for _ in open(os.path.join(out, "out_r2.txt")))
+    print(f"soap: {len(reads)} reads, {rows} rows (-r 2)")
