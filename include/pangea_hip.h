@@ -1,0 +1,248 @@
+/*
+ * pangea_hip.h — C ABI of libpangea_hip.so, the MI355X (gfx950) classification-and-consensus
+ * engine that replaces ONE hot path of PANGEA+ :
+ *
+ *     Classify/{Runblast,Runsoap}  ->  Tax_class/ncbitc.c (+ NCBI-taxcollector-0.01.pl)
+ *                                  ->  Consensus/Consensus_BLAST_SOAP_RDP-1.1.pl
+ *
+ * The reference has no library / plugin / FFI API: its boundary is process + argv + files +
+ * stdout.  Each entry point below is therefore the in-process equivalent of one
+ * reference command line, cited as file:line relative to the reference tree; the thin CLIs
+ * under pangea-plus_amd/cli/ map argv onto them and print the reference's bytes.
+ *
+ * Conventions: plain C types only; every function returns 0 or a negative pgx_status and
+ * records a message retrievable with pgx_last_error() (thread local).  The caller owns every
+ * path and buffer it passes; the library owns the opaque handles until the matching *_close.
+ * All compute runs on the GPU selected with pgx_init(); there is NO CPU fallback: without a
+ * usable HIP device every compute entry point fails with PGX_E_NODEVICE.
+ */
+#ifndef PANGEA_HIP_H
+#define PANGEA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	PGX_OK = 0,
+	PGX_E_ARG = -1,       /* bad argument */
+	PGX_E_IO = -2,        /* file cannot be opened / read / written */
+	PGX_E_NODEVICE = -3,  /* no usable gfx950 device, or a HIP call failed */
+	PGX_E_FORMAT = -4,    /* malformed input */
+	PGX_E_NOMEM = -5,
+	PGX_E_REFHANG = -6,   /* input on which the reference never terminates */
+	PGX_E_LIMIT = -7      /* documented limit exceeded */
+} pgx_status;
+
+const char *pgx_last_error(void);
+const char *pgx_version(void);
+/* Select the HIP device for the calling process (one process per GPU). */
+int pgx_init(int device);
+int pgx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Sequence database  —  `makeblastdb -in nt -out nt -dbtype nucl` (README.md:62) and
+ * `2bwt-builder ref.fasta` (README.md:130).  One on-disk format serves both classify modes:
+ * <prefix>.pgxdb = header, 2-bit packed bases, ambiguity runs, sequence offsets, ids.
+ * The k-mer seed index is built on the device when the database is opened.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pgx_db pgx_db;
+int pgx_db_build(const char *fasta_path, const char *prefix);
+int pgx_db_open(const char *prefix, pgx_db **out);
+int pgx_db_from_fasta(const char *fasta_path, pgx_db **out); /* build + open without the file */
+void pgx_db_close(pgx_db *db);
+int64_t pgx_db_num_seqs(const pgx_db *db);
+int64_t pgx_db_num_bases(const pgx_db *db);
+/* id (first word of the header) of subject i; pointer valid until pgx_db_close */
+const char *pgx_db_seq_id(const pgx_db *db, int64_t i);
+
+/* Device-resident arrays of an open database, for the one-off RCCL broadcast of the index
+ * (SURVEY 5.8 / 8e).  `ptr` are device addresses owned by the handle. */
+typedef struct {
+	const char *name;
+	void *ptr;
+	size_t bytes;
+} pgx_device_array;
+int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap); /* returns count */
+/* A receiving rank allocates an empty database of the same shape, the caller broadcasts into
+ * its arrays, then pgx_db_finish_import() makes it usable. */
+typedef struct {
+	int64_t n_seq, n_bases;
+	int32_t has_amb, index_bits;
+	int64_t n_postings;
+} pgx_db_shape;
+int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out);
+int pgx_db_alloc_like(const pgx_db_shape *shape, pgx_db **out);
+int pgx_db_finish_import(pgx_db *db);
+
+/* ------------------------------------------------------------------------------------------
+ * Classify, BLAST verb  —  `blastn -query F -db DB -outfmt 6 -out O` (README.md:96;
+ * Scripts/run_multi_blastn.pl:56) and `mpiblastn in.fasta db out.txt N`
+ * (Scripts/submit_MPI-blast.job:24).  Semantics: spec "pgx-blastn v1" (DESIGN.md); BLAST+
+ * itself is not vendored by the reference, so parity with NCBI's binary is unpinned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	const char *query_path; /* -query */
+	const char *db_prefix;  /* -db    */
+	const char *out_path;   /* -out   */
+	int outfmt;             /* -outfmt, only 6 */
+	int rank, world_size;   /* read sharding: this process handles block `rank` of `world_size` */
+} pgx_blastn_opts;
+int pgx_blastn_run(const pgx_blastn_opts *opts);
+
+/* ------------------------------------------------------------------------------------------
+ * Classify, SOAP verb  —  `soap -a reads -D ref.index -o out -p 8 -M 4` (README.md:134;
+ * flags soap.man:29-83).  Behaviour pinned by golden vectors from the reference's ELF.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	const char *reads_path;    /* -a */
+	const char *db_prefix;     /* -D (with or without the ".index" suffix) */
+	const char *out_path;      /* -o */
+	const char *unmapped_path; /* -u, may be NULL */
+	int match_mode;            /* -M, only 4 (best hits) */
+	int repeat_mode;           /* -r 0|1|2, default 1 */
+	int max_n;                 /* -n, default 5 */
+	int report_id;             /* -t */
+} pgx_soap_opts;
+int pgx_soap_index(const char *fasta_path); /* writes <fasta>.index.pgxdb */
+int pgx_soap_run(const pgx_soap_opts *opts);
+
+/* ------------------------------------------------------------------------------------------
+ * Taxonomy database  —  Tax_class/ncbitc.c.  Same file names in `dir` as the reference
+ * keeps in its cwd (ncbitc.c:7-13) and byte-compatible .bin files (ncbitc.c:98-140).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pgx_taxdb pgx_taxdb;
+typedef struct {
+	int32_t tax_id, parent_tax_id;
+	int8_t rank; /* enum order of ncbitc.c:39-69; -1 unknown */
+	char embl_code[3];
+	int16_t division_id;
+	int8_t inherited_div_flag;
+	int16_t genetic_code_id;
+	int8_t inherited_GC_flag;
+	int32_t mitochondrial_genetic_code_id;
+	int8_t inherited_MGC_flag, GenBank_hidden_flag, hidden_subtree_root_flag;
+} pgx_node; /* == struct nodes_dmp, 28 bytes */
+typedef struct {
+	int32_t tax_id;
+	char name_txt[64], unique_name[64], name_class[64];
+} pgx_name; /* == struct names_dmp, 196 bytes */
+
+int pgx_tax_create(const char *dir);                    /* tax_class -c   (ncbitc.c:701-839, 995-998) */
+int pgx_tax_open(const char *dir, pgx_taxdb **out);     /* loads the .bin files, uploads parent/rank arrays */
+void pgx_tax_close(pgx_taxdb *db);
+int pgx_tax_gi2taxid(const pgx_taxdb *db, int gi, int *taxid);          /* ncbitc.c:567-599 */
+int pgx_tax_node(const pgx_taxdb *db, int taxid, pgx_node *out);        /* ncbitc.c:601-628 */
+int pgx_tax_names(const pgx_taxdb *db, int taxid, pgx_name *buf, int cap); /* ncbitc.c:647-699; returns count */
+int pgx_tax_format_node(const pgx_node *n, char *buf, size_t cap);      /* ncbitc.c:467-493 */
+int pgx_tax_format_name(const pgx_name *n, char *buf, size_t cap);      /* ncbitc.c:559-565 */
+/* the whole command line of ncbitc.c:860-1004; stdout/stderr text into malloc'd strings the
+ * caller frees with pgx_free; returns the process exit status */
+int pgx_tax_cli(int argc, char **argv, const char *dir, char **out_text, char **err_text);
+void pgx_free(void *p);
+
+/* Batched device lineage walk: for n GIs, gi -> taxid -> parent chain, keeping the nodes whose
+ * rank is one of the 8 the driver prints (NCBI-taxcollector-0.01.pl:228-237), leaf first as
+ * the Perl pushes them.  lineage[i*PGX_LINEAGE_SLOTS + k] = taxid of the k-th kept node, or
+ * PGX_LIN_UNCLASSIFIED for the "[0]Unclassified;" element (taxcollector:289-290);
+ * count[i] = number of elements (0 with status[i] != 0 when the gi has taxid 0 or the walk is
+ * one the reference cannot finish).  Host pointers in, host pointers out. */
+#define PGX_LINEAGE_SLOTS 16
+#define PGX_LIN_UNCLASSIFIED (-2)
+int pgx_tax_lineage_batch(pgx_taxdb *db, const int32_t *gi, int64_t n, int32_t *lineage, int32_t *count,
+			  int32_t *status);
+
+/* Tax annotate  —  `perl NCBI-taxcollector-0.01.pl -f in.tsv -o out.tsv > report.txt`
+ * (README.md:109; NCBI-taxcollector-0.01.pl:20-164).  `report` receives the stdout text. */
+int pgx_taxcollect_file(pgx_taxdb *db, const char *in_path, const char *out_path, char **report_text);
+
+/* ------------------------------------------------------------------------------------------
+ * Consensus  —  `perl Consensus_BLAST_SOAP_RDP-1.1.pl -b B -r R [-s S] -o O`
+ * (README.md:152; Consensus_BLAST_SOAP_RDP-1.1.pl:8-244).  -s is opened and never read, as
+ * in the reference (Consensus:40-46).  `log_text` receives the stdout text.
+ * ------------------------------------------------------------------------------------------ */
+int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, const char *o, char **log_text);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused device pipeline  (classify -> lineage -> consensus without intermediate files) and
+ * the synthetic workload of BASELINE.md section 3, used by bench.py and the parity tests.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	uint64_t seed;      /* 0x50414E47 */
+	int64_t n_seq;      /* 666667 */
+	int32_t seq_len;    /* 1500 */
+	int64_t n_genus;    /* 20000 */
+	uint64_t read_seed; /* 42 */
+	int32_t read_len;   /* 150 */
+} pgx_synth_cfg;
+void pgx_synth_default(pgx_synth_cfg *cfg);
+/* database generated directly in HBM (headers "gi|<1000+i>|syn|S<i>|"), index built on device */
+int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out);
+/* nodes.dmp / names.dmp / gi_taxid_nucl.dmp of the synthetic taxonomy, written to dir */
+int pgx_synth_write_taxdump(const pgx_synth_cfg *cfg, const char *dir);
+
+typedef struct pgx_reads pgx_reads; /* a batch of reads resident in HBM, both strands packed */
+int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_reads **out);
+int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, pgx_reads **out);
+void pgx_reads_close(pgx_reads *r);
+int64_t pgx_reads_count(const pgx_reads *r);
+/* packed bases of read i (2 bits per base, 32 per word, low bits first) for parity checks */
+int pgx_reads_get(const pgx_reads *r, int64_t i, uint8_t *bases_out, int32_t cap, int32_t *len_out);
+
+typedef struct {
+	int32_t read, subject;
+	int32_t qstart, qend; /* 1-based, plus-strand query coordinates */
+	int32_t sstart, send; /* 1-based; sstart > send on the minus strand */
+	int32_t score;        /* raw: matches - 2 * mismatches */
+	int32_t mismatch;
+} pgx_hit; /* alignment length = qend - qstart + 1 */
+
+typedef struct pgx_hits pgx_hits; /* device hit table of one batch, in -outfmt 6 order */
+int pgx_blast_search(pgx_db *db, pgx_reads *reads, pgx_hits **out);
+void pgx_hits_close(pgx_hits *h);
+int64_t pgx_hits_count(const pgx_hits *h);
+int pgx_hits_copy(const pgx_hits *h, pgx_hit *out, int64_t cap);           /* device -> host */
+int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap);   /* n_reads+1 offsets */
+/* -outfmt 6 text of the table, malloc'd (pgx_free) */
+int pgx_hits_format(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, char **text, size_t *len);
+
+/* subject -> lineage binding: resolves every subject id "gi|N|..." through the taxonomy on the
+ * device (one walk per subject) and keeps per-subject lineage text + token ids in HBM */
+int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax);
+const char *pgx_db_subject_lineage(const pgx_db *db, int64_t subject);
+
+/* RDP stream of a read batch: the five-tab text format (Consensus:126-132) or the synthetic one */
+typedef struct pgx_rdp pgx_rdp;
+int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *db, pgx_rdp **out);
+int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, const pgx_db *db, pgx_rdp **out);
+void pgx_rdp_close(pgx_rdp *r);
+
+typedef struct {
+	int32_t hit;     /* index into the hit table of the winning hit, -1 when the read has none */
+	int32_t matches; /* "#Matches found: N" */
+} pgx_consensus_rec;
+/* per read: Consensus arg-max over the read's hits (Consensus:141-234) on the device */
+int pgx_consensus_batch(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *out,
+			int64_t cap);
+/* the whole hot path for one resident batch: search + lineage + consensus, results left in HBM;
+ * `out` may be NULL (bench) */
+int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx_hits **hits_out,
+			   pgx_consensus_rec *out, int64_t cap);
+/* consensus text ("<hit line with lineage>\n#Matches found: N\n" per read), malloc'd */
+int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
+			 const pgx_consensus_rec *recs, int64_t n, char **text, size_t *len);
+
+/* instrumentation for bench.py: HIP-event time (ms) of the kernels of the last pipeline call */
+typedef struct {
+	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;
+	int64_t probes, postings, candidates, hits;
+} pgx_stage_times;
+int pgx_last_stage_times(pgx_stage_times *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANGEA_HIP_H */

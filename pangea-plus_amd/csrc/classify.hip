@@ -1,0 +1,972 @@
+// Classify kernels, BLAST mode (spec pgx-blastn v1) and the per-read consensus.
+//
+// Replaces the arithmetic of `blastn -query F -db DB -outfmt 6` (reference README.md:96,
+// Scripts/run_multi_blastn.pl:56, Scripts/submit_MPI-blast.job:24) and the per-read arg-max of
+// Consensus/Consensus_BLAST_SOAP_RDP-1.1.pl:141-234.
+//
+// k_seed_extend   one wavefront per read.  Lanes first act as PROBES: the 16-mers at stride 13 of
+//                 both strands are looked up in the direct-address bucket table (one dependent
+//                 gather each).  The posting counts are prefix-summed across the wave and the
+//                 postings are then dealt to the 64 lanes as CANDIDATES, so a read with 3 or
+//                 3 000 postings keeps every lane busy.  A candidate lane builds the mismatch
+//                 words of its diagonal on demand (packed read XOR funnel-shifted database
+//                 window), rejects duplicates without any sort (only the left-most probe of the
+//                 first >=28 run of a diagonal reports it) and does the X-drop extension on the
+//                 bit masks.  Hits are staged in LDS per wave and appended to the global table
+//                 with one atomic per flush.
+// k_sort_consensus one wavefront per read: hits in LDS, rank sort into the -outfmt 6 order, then
+//                 (rank,name) agreement with the RDP assignment per hit and the order-dependent
+//                 arg-max with the Perl's string comparisons.
+#include <algorithm>
+
+#include "bitops.hpp"
+#include "engine.hpp"
+
+namespace pgx {
+
+struct DbView {
+	const uint64_t *words, *amb;
+	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
+	uint32_t n_seq;
+	int bits;
+};
+
+struct ReadsView {
+	const uint64_t *fwd, *rc, *fwd_amb, *rc_amb;
+	const uint32_t *len, *woff;
+	uint32_t n;
+};
+
+// ------------------------------------------------------------------------------------------ diagonal masks
+struct Diag {
+	const uint64_t *rw, *ra;   // read words / spaced ambiguity flags of the strand (ra may be null)
+	const uint64_t *dbw, *dba; // database words / flags (dba may be null)
+	int64_t dstart;            // database position aligned with read position 0
+	int lo, hi;                // read positions [lo, hi) lie inside the subject
+};
+
+// spaced mismatch flags of read bases [32w, 32w+32); bases outside [lo, hi) are flagged
+template <bool AMB> __device__ __forceinline__ uint64_t mmw(const Diag &D, int w)
+{
+	int b0 = 32 * w;
+	if (b0 + 32 <= D.lo || b0 >= D.hi)
+		return kEven;
+	uint64_t x = D.rw[w] ^ window64(D.dbw, D.dstart + b0);
+	uint64_t m = (x | (x >> 1)) & kEven;
+	if (AMB) {
+		if (D.ra)
+			m |= D.ra[w];
+		if (D.dba)
+			m |= window64(D.dba, D.dstart + b0);
+	}
+	m |= kEven & ~spaced_range(D.lo - b0, D.hi - b0);
+	return m;
+}
+
+// smallest flagged position >= pos, or hi
+template <bool AMB> __device__ __forceinline__ int first_mm_ge(const Diag &D, int pos)
+{
+	if (pos >= D.hi)
+		return D.hi;
+	int w = pos >> 5;
+	uint64_t m = mmw<AMB>(D, w) & ~((1ull << (2 * (pos & 31))) - 1);
+	while (!m) {
+		w++;
+		if (32 * w >= D.hi)
+			return D.hi;
+		m = mmw<AMB>(D, w);
+	}
+	int r = 32 * w + ((__ffsll((unsigned long long)m) - 1) >> 1);
+	return r < D.hi ? r : D.hi;
+}
+
+// largest flagged position < pos, or lo-1
+template <bool AMB> __device__ __forceinline__ int last_mm_lt(const Diag &D, int pos)
+{
+	if (pos <= D.lo)
+		return D.lo - 1;
+	int q = pos - 1, w = q >> 5, bit = q & 31;
+	uint64_t keep = bit == 31 ? ~0ull : ((1ull << (2 * bit + 2)) - 1);
+	uint64_t m = mmw<AMB>(D, w) & keep;
+	while (!m) {
+		if (32 * w <= D.lo)
+			return D.lo - 1;
+		w--;
+		m = mmw<AMB>(D, w);
+	}
+	int r = 32 * w + ((63 - __clzll((long long)m)) >> 1);
+	return r >= D.lo ? r : D.lo - 1;
+}
+
+constexpr int kStage = 128; // hits staged in LDS per wave between flushes
+constexpr int kWavesPerBlock = 4;
+
+struct WaveStage {
+	pgx_hit hit[kStage];
+	unsigned int n;      // staged
+	unsigned int direct; // emitted straight to HBM because the stage was full
+};
+
+__device__ __forceinline__ void emit_hit(WaveStage *st, pgx_hit *hits, unsigned long long cap,
+					  unsigned long long *hit_count, const pgx_hit &h)
+{
+	unsigned int slot = atomicAdd(&st->n, 1u);
+	if (slot < (unsigned)kStage) {
+		st->hit[slot] = h;
+	} else {
+		atomicAdd(&st->direct, 1u);
+		unsigned long long g = atomicAdd(hit_count, 1ull);
+		if (g < cap)
+			hits[g] = h;
+	}
+}
+
+template <bool AMB>
+__device__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read, int strand,
+				  int qp, uint32_t p, WaveStage *st, pgx_hit *hits, unsigned long long cap,
+				  unsigned long long *hit_count)
+{
+	uint32_t s = db.blk_subj[p >> 6];
+	while (db.seq_off[s + 1] <= p)
+		s++;
+	const uint32_t s_start = db.seq_off[s], s_end = db.seq_off[s + 1];
+	if (p + (uint32_t)kSeedK > s_end)
+		return; // seed straddles two subjects
+	Diag D;
+	D.rw = rw;
+	D.ra = ra;
+	D.dbw = db.words;
+	D.dba = db.amb;
+	D.dstart = (int64_t)p - qp;
+	int64_t lo64 = (int64_t)s_start - D.dstart, hi64 = (int64_t)s_end - D.dstart;
+	D.lo = lo64 > 0 ? (int)lo64 : 0;
+	D.hi = hi64 < L ? (int)hi64 : L;
+
+	// (1) only the left-most probe inside an exact run reports that run
+	const int lm = last_mm_lt<AMB>(D, qp);
+	if (qp >= kProbeStride && lm < qp - kProbeStride)
+		return;
+	// (2) the probe 16-mer itself must match (bucket collisions, ambiguity, boundaries)
+	const int re = first_mm_ge<AMB>(D, qp);
+	if (re < qp + kSeedK)
+		return;
+	const int run_start = lm + 1;
+	if (re - run_start < kWord)
+		return;
+	// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
+	int pos = D.lo;
+	while (pos < run_start) {
+		int m1 = first_mm_ge<AMB>(D, pos);
+		if (m1 - pos >= kWord)
+			return;
+		pos = m1 + 1;
+	}
+	// (4) spec S3: seeds left to right, X-drop extension on the mismatch masks
+	int covered = D.lo;
+	pos = run_start;
+	while (pos < D.hi) {
+		const int e = first_mm_ge<AMB>(D, pos);
+		const int len = e - pos;
+		if (len >= kWord && pos >= covered) {
+			int best = 0, cur = 0, bl = pos, nmm = 0, mm_best = 0;
+			int k = pos - 1; // a flagged position, or lo-1
+			while (k >= D.lo) {
+				cur -= 2;
+				nmm++;
+				if (best - cur > kXdrop)
+					break;
+				int p2 = last_mm_lt<AMB>(D, k);
+				int n = k - 1 - p2;
+				if (n > 0) {
+					cur += n;
+					if (cur > best) {
+						best = cur;
+						bl = p2 + 1;
+						mm_best = nmm;
+					}
+				}
+				k = p2;
+			}
+			int bestr = 0, br = e - 1, mmr_best = 0;
+			cur = 0;
+			nmm = 0;
+			k = e; // a flagged position, or hi
+			while (k < D.hi) {
+				cur -= 2;
+				nmm++;
+				if (bestr - cur > kXdrop)
+					break;
+				int n2 = first_mm_ge<AMB>(D, k + 1);
+				int n = n2 - (k + 1);
+				if (n > 0) {
+					cur += n;
+					if (cur > bestr) {
+						bestr = cur;
+						br = n2 - 1;
+						mmr_best = nmm;
+					}
+				}
+				k = n2;
+			}
+			pgx_hit h;
+			h.read = (int32_t)read;
+			h.subject = (int32_t)s;
+			h.score = len + best + bestr;
+			h.mismatch = mm_best + mmr_best;
+			const int64_t sl = D.dstart + bl - (int64_t)s_start + 1, sr = D.dstart + br - (int64_t)s_start + 1;
+			if (!strand) {
+				h.qstart = bl + 1;
+				h.qend = br + 1;
+				h.sstart = (int32_t)sl;
+				h.send = (int32_t)sr;
+			} else {
+				h.qstart = L - br;
+				h.qend = L - bl;
+				h.sstart = (int32_t)sr;
+				h.send = (int32_t)sl;
+			}
+			emit_hit(st, hits, cap, hit_count, h);
+			covered = br + 1;
+		}
+		pos = e + 1;
+	}
+}
+
+__device__ __forceinline__ void lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// counters: [0] hits appended, [1] probes, [2] postings, [3] candidates that passed (1)-(3)
+template <bool AMB>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, ReadsView rd, pgx_hit *hits,
+								      unsigned long long cap,
+								      unsigned long long *counters,
+								      uint32_t *read_cnt)
+{
+	__shared__ WaveStage s_stage[kWavesPerBlock];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	WaveStage *st = &s_stage[wave];
+	unsigned long long n_probe = 0, n_post = 0;
+
+	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
+		const int L = (int)rd.len[r];
+		const uint32_t w0 = rd.woff[r];
+		const int nps = L >= kSeedK ? (L - kSeedK) / kProbeStride + 1 : 0;
+		const int P = 2 * nps;
+		unsigned int emitted = 0;
+		if (lane == 0) {
+			st->n = 0;
+			st->direct = 0;
+		}
+		lds_fence();
+		for (int pbase = 0; pbase < P; pbase += 64) {
+			const int pid = pbase + lane;
+			uint32_t cnt = 0, lo = 0;
+			int strand = 0, qpos = 0;
+			if (pid < P) {
+				strand = pid >= nps;
+				qpos = (pid - strand * nps) * kProbeStride;
+				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
+				bool ok = true;
+				if (AMB) {
+					const uint64_t *ra = strand ? rd.rc_amb : rd.fwd_amb;
+					if (ra && (uint32_t)window64(ra + w0, qpos))
+						ok = false;
+				}
+				if (ok) {
+					uint32_t b = seed_bucket(kmer16(rw, qpos), db.bits);
+					lo = db.bucket_off[b];
+					cnt = db.bucket_off[(uint64_t)b + 1] - lo;
+				}
+			}
+			// wave prefix sum of the posting counts
+			uint32_t incl = cnt;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				uint32_t t = __shfl_up(incl, d);
+				if (lane >= d)
+					incl += t;
+			}
+			const uint32_t excl = incl - cnt;
+			const uint32_t T = __shfl(incl, 63);
+			n_probe += (pid < P);
+			n_post += cnt;
+			for (uint32_t it = 0; it < T; it += 64) {
+				const uint32_t item = it + lane;
+				const bool active = item < T;
+				const uint32_t key = active ? item : T - 1;
+				// owner probe: the last lane whose exclusive prefix is <= item
+				int o = 0;
+#pragma unroll
+				for (int step = 32; step >= 1; step >>= 1) {
+					int cand = o + step;
+					uint32_t e = __shfl(excl, cand & 63);
+					if (cand < 64 && e <= key)
+						o = cand;
+				}
+				const uint32_t o_excl = __shfl(excl, o), o_lo = __shfl(lo, o);
+				const int o_strand = __shfl(strand, o), o_qpos = __shfl(qpos, o);
+				if (active) {
+					const uint32_t p = db.postings[o_lo + (key - o_excl)];
+					const uint64_t *rw = (o_strand ? rd.rc : rd.fwd) + w0;
+					const uint64_t *ra = nullptr;
+					if (AMB) {
+						const uint64_t *a = o_strand ? rd.rc_amb : rd.fwd_amb;
+						ra = a ? a + w0 : nullptr;
+					}
+					process_candidate<AMB>(db, rw, ra, L, r, o_strand, o_qpos, p, st, hits, cap, &counters[0]);
+				}
+				lds_fence();
+				// flush the stage when it is more than half full (wave-uniform decision)
+				unsigned int n = st->n;
+				if (n > (unsigned)kStage / 2) {
+					if (n > (unsigned)kStage)
+						n = kStage;
+					unsigned long long base = 0;
+					if (lane == 0)
+						base = atomicAdd(&counters[0], (unsigned long long)n);
+					base = __shfl(base, 0);
+					for (unsigned int i = lane; i < n; i += 64)
+						if (base + i < cap)
+							hits[base + i] = st->hit[i];
+					emitted += n;
+					lds_fence();
+					if (lane == 0)
+						st->n = 0;
+					lds_fence();
+				}
+			}
+		}
+		lds_fence();
+		unsigned int n = st->n;
+		if (n > (unsigned)kStage)
+			n = kStage;
+		if (n) {
+			unsigned long long base = 0;
+			if (lane == 0)
+				base = atomicAdd(&counters[0], (unsigned long long)n);
+			base = __shfl(base, 0);
+			for (unsigned int i = lane; i < n; i += 64)
+				if (base + i < cap)
+					hits[base + i] = st->hit[i];
+			emitted += n;
+		}
+		emitted += st->direct;
+		if (lane == 0)
+			read_cnt[r] = emitted;
+		lds_fence();
+	}
+	// per-wave statistics (a handful of atomics per wave, not per read)
+	for (int d = 32; d >= 1; d >>= 1) {
+		n_probe += __shfl_down(n_probe, d);
+		n_post += __shfl_down(n_post, d);
+	}
+	if (lane == 0) {
+		atomicAdd(&counters[1], n_probe);
+		atomicAdd(&counters[2], n_post);
+	}
+}
+
+// ------------------------------------------------------------------------------------------ grouping by read
+constexpr int kScanBlock = 256, kScanItems = 8; // 2048 counts per block
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_partials(const uint32_t *__restrict__ cnt, uint64_t n,
+							      uint32_t *__restrict__ partial)
+{
+	__shared__ uint32_t s[kScanBlock];
+	uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
+	uint32_t sum = 0;
+	for (int k = 0; k < kScanItems; k++) {
+		uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + k;
+		if (i < n)
+			sum += cnt[i];
+	}
+	s[threadIdx.x] = sum;
+	__syncthreads();
+	for (int d = kScanBlock / 2; d >= 1; d >>= 1) {
+		if ((int)threadIdx.x < d)
+			s[threadIdx.x] += s[threadIdx.x + d];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		partial[blockIdx.x] = s[0];
+}
+
+// exclusive scan of the block partials by one block (chunks of 256 with a running carry)
+__global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t *__restrict__ partial, uint32_t n_part)
+{
+	__shared__ uint32_t s[kScanBlock];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0)
+		carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < n_part; base += kScanBlock) {
+		uint32_t i = base + threadIdx.x;
+		uint32_t v = i < n_part ? partial[i] : 0;
+		s[threadIdx.x] = v;
+		__syncthreads();
+		for (int d = 1; d < kScanBlock; d <<= 1) {
+			uint32_t t = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+			__syncthreads();
+			s[threadIdx.x] += t;
+			__syncthreads();
+		}
+		uint32_t incl = s[threadIdx.x];
+		if (i < n_part)
+			partial[i] = carry + incl - v;
+		__syncthreads();
+		if (threadIdx.x == kScanBlock - 1)
+			carry += incl;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_final(const uint32_t *__restrict__ cnt, uint64_t n,
+							   const uint32_t *__restrict__ partial, uint32_t *__restrict__ off)
+{
+	__shared__ uint32_t s[kScanBlock];
+	uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
+	uint32_t v[kScanItems], sum = 0;
+	for (int k = 0; k < kScanItems; k++) {
+		uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + k;
+		v[k] = i < n ? cnt[i] : 0;
+		sum += v[k];
+	}
+	s[threadIdx.x] = sum;
+	__syncthreads();
+	for (int d = 1; d < kScanBlock; d <<= 1) {
+		uint32_t t = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+		__syncthreads();
+		s[threadIdx.x] += t;
+		__syncthreads();
+	}
+	uint32_t run = partial[blockIdx.x] + s[threadIdx.x] - sum;
+	for (int k = 0; k < kScanItems; k++) {
+		uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + k;
+		if (i < n)
+			off[i] = run;
+		run += v[k];
+	}
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanBlock - 1)
+		off[n] = run;
+}
+
+__global__ void k_scatter_hits(const pgx_hit *__restrict__ in, uint64_t n_hits, const uint32_t *__restrict__ off,
+			       uint32_t *__restrict__ cursor, pgx_hit *__restrict__ out)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n_hits; i += stride) {
+		pgx_hit h = in[i];
+		uint32_t slot = off[h.read] + atomicAdd(&cursor[h.read], 1u);
+		out[slot] = h;
+	}
+}
+
+// ------------------------------------------------------------------------------------------ per-read order + consensus
+// spec S5 order inside one read; `ba`/`bb` are the best scores of the hits' subjects
+__device__ __forceinline__ bool hit_less(const pgx_hit &a, int ba, const pgx_hit &b, int bb)
+{
+	if (ba != bb)
+		return ba > bb;
+	if (a.subject != b.subject)
+		return a.subject < b.subject;
+	if (a.score != b.score)
+		return a.score > b.score;
+	if (a.qstart != b.qstart)
+		return a.qstart < b.qstart;
+	if (a.qend != b.qend)
+		return a.qend < b.qend;
+	if (a.sstart != b.sstart)
+		return a.sstart < b.sstart;
+	return a.send < b.send;
+}
+
+// Perl `gt` on the decimal texts of two non-negative integers (Consensus:191,199)
+__device__ __forceinline__ bool dec_str_gt(uint32_t a, uint32_t b)
+{
+	if (a == b)
+		return false;
+	uint32_t pa = 1, pb = 1; // 10^(digits-1)
+	while (a / pa >= 10)
+		pa *= 10;
+	while (b / pb >= 10)
+		pb *= 10;
+	// compare digit by digit from the most significant
+	while (pa && pb) {
+		uint32_t da = (a / pa) % 10, db = (b / pb) % 10;
+		if (da != db)
+			return da > db;
+		pa /= 10;
+		pb /= 10;
+	}
+	return pa != 0; // the longer text wins when the shorter is its prefix
+}
+
+struct ConsView {
+	const uint32_t *subj_tok_off, *subj_tok; // per subject token ids
+	const int8_t *tok_rank;                  // token id -> index in "0".."6" or -1
+	const uint32_t *simrank_lut;             // pident hundredths -> string-order rank
+	uint32_t simrank_undef, simrank_zero;
+	const uint32_t *rdp_off, *rdp_name;
+	const int8_t *rdp_rank;
+	const uint8_t *rdp_present;
+};
+
+// (rank,name) agreement of one hit with the read's RDP triplets (Consensus:154-184)
+__device__ __forceinline__ uint32_t rank_matches(const ConsView &cv, uint32_t subject, uint32_t r0, uint32_t r1,
+						  uint32_t *ntok_out)
+{
+	const uint32_t t0 = cv.subj_tok_off[subject], t1 = cv.subj_tok_off[subject + 1];
+	*ntok_out = t1 - t0;
+	uint32_t rm = 0;
+	for (uint32_t a = t0; a < t1; a += 2) {
+		const int i1 = cv.tok_rank[cv.subj_tok[a]];
+		const uint32_t name = a + 1 < t1 ? cv.subj_tok[a + 1] : 0u; // undef stringifies to ""
+		for (uint32_t b = r0; b < r1; b++)
+			rm += (name == cv.rdp_name[b]) && (i1 == (int)cv.rdp_rank[b]);
+	}
+	return rm;
+}
+
+constexpr int kSortCap = 256; // hits of one read held in LDS by its wave
+
+struct SortWave {
+	pgx_hit hit[kSortCap];
+	int best[kSortCap];
+	uint32_t rm[kSortCap], ntok[kSortCap], sim[kSortCap]; // indexed by final rank
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit *__restrict__ hits,
+									 const uint32_t *__restrict__ off,
+									 uint32_t *__restrict__ read_cnt, uint32_t n_reads,
+									 ConsView cv, int do_consensus,
+									 pgx_consensus_rec *__restrict__ recs,
+									 uint32_t *__restrict__ big_list,
+									 uint32_t *__restrict__ big_count)
+{
+	extern __shared__ unsigned char s_raw[];
+	SortWave *sw = reinterpret_cast<SortWave *>(s_raw) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	for (uint32_t r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); r < n_reads; r += gridDim.x * kWavesPerBlock) {
+		const uint32_t o = off[r], n = off[r + 1] - o;
+		if (n == 0) {
+			if (do_consensus && lane == 0) {
+				recs[r].hit = -2;
+				recs[r].matches = 0;
+			}
+			continue;
+		}
+		if (n > (uint32_t)kSortCap) {
+			if (lane == 0)
+				big_list[atomicAdd(big_count, 1u)] = r;
+			continue;
+		}
+		for (uint32_t i = lane; i < n; i += 64)
+			sw->hit[i] = hits[o + i];
+		lds_fence();
+		// best score of each hit's subject
+		for (uint32_t i = lane; i < n; i += 64) {
+			const int subj = sw->hit[i].subject;
+			int b = sw->hit[i].score;
+			for (uint32_t j = 0; j < n; j++)
+				if (sw->hit[j].subject == subj && sw->hit[j].score > b)
+					b = sw->hit[j].score;
+			sw->best[i] = b;
+		}
+		lds_fence();
+		// rank = number of hits that precede this one
+		for (uint32_t i = lane; i < n; i += 64) {
+			const pgx_hit h = sw->hit[i];
+			const int b = sw->best[i];
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < n; j++)
+				rank += (j != i) && (hit_less(sw->hit[j], sw->best[j], h, b) ||
+						     (!hit_less(h, b, sw->hit[j], sw->best[j]) && j < i));
+			hits[o + rank] = h;
+			if (do_consensus) {
+				uint32_t ntok;
+				const uint32_t r0 = cv.rdp_off[r], r1 = cv.rdp_off[r + 1];
+				sw->rm[rank] = rank_matches(cv, (uint32_t)h.subject, r0, r1, &ntok);
+				sw->ntok[rank] = ntok;
+				const int len = h.qend - h.qstart + 1;
+				sw->sim[rank] = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
+			}
+		}
+		lds_fence();
+		if (do_consensus && lane == 0) {
+			// Consensus:186-204, strictly in table order
+			pgx_consensus_rec rec;
+			rec.hit = -1;
+			rec.matches = 0;
+			if (cv.rdp_present && !cv.rdp_present[r]) {
+				rec.hit = -2;
+			} else {
+				uint32_t maxrm = 0, maxcnt = 0, cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+				for (uint32_t k = 0; k < n; k++) {
+					const uint32_t rm = sw->rm[k], c = sw->ntok[k], sim = sw->sim[k];
+					if (dec_str_gt(rm, maxrm)) {
+						maxrm = rm;
+						rec.hit = (int32_t)(o + k);
+						cursim = sim;
+					}
+					if ((dec_str_gt(c, maxcnt) || cursim < sim) && rm == maxrm) {
+						maxcnt = c;
+						rec.hit = (int32_t)(o + k);
+						cursim = sim;
+					}
+				}
+				rec.matches = (int32_t)maxrm;
+			}
+			recs[r] = rec;
+		}
+		lds_fence();
+	}
+}
+
+// Reads with more hits than the LDS path holds: one block per read, all-pairs ranking through
+// global memory (correct for any size; quadratic, a known cost for pathological reads).
+__global__ __launch_bounds__(256) void k_sort_big(const pgx_hit *__restrict__ in, pgx_hit *__restrict__ out,
+						  const uint32_t *__restrict__ off, uint32_t *__restrict__ read_cnt,
+						  const uint32_t *__restrict__ big_list, uint32_t n_big, int *__restrict__ best_ws)
+{
+	for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+		const uint32_t r = big_list[bi], o = off[r], n = off[r + 1] - o;
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+			const int subj = in[o + i].subject;
+			int b = in[o + i].score;
+			for (uint32_t j = 0; j < n; j++)
+				if (in[o + j].subject == subj && in[o + j].score > b)
+					b = in[o + j].score;
+			best_ws[o + i] = b;
+		}
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+			const pgx_hit h = in[o + i];
+			const int b = best_ws[o + i];
+			uint32_t rank = 0;
+			for (uint32_t j = 0; j < n; j++) {
+				const pgx_hit g = in[o + j];
+				const int bj = best_ws[o + j];
+				rank += (j != i) && (hit_less(g, bj, h, b) || (!hit_less(h, b, g, bj) && j < i));
+			}
+			out[o + rank] = h;
+		}
+		__syncthreads();
+		// spec S5: at most 500 subjects; subjects are contiguous in the order, dropped hits are its tail
+		if (threadIdx.x == 0) {
+			uint32_t keep = n, subjects = 0;
+			int prev = -1;
+			for (uint32_t k = 0; k < n; k++) {
+				const int sj = out[o + k].subject;
+				if (sj != prev) {
+					prev = sj;
+					if (++subjects > 500u) {
+						keep = k;
+						break;
+					}
+				}
+			}
+			read_cnt[r] = keep;
+		}
+		__syncthreads();
+	}
+}
+
+// consensus for the big reads and for file mode (hits already in order): one lane per read
+__global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint32_t *__restrict__ off,
+				   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ list, uint32_t n_list,
+				   ConsView cv, pgx_consensus_rec *__restrict__ recs)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_list)
+		return;
+	const uint32_t r = list ? list[t] : t;
+	const uint32_t o = off[r], n = cnt[r];
+	pgx_consensus_rec rec;
+	rec.hit = n ? -1 : -2;
+	rec.matches = 0;
+	if (cv.rdp_present && !cv.rdp_present[r])
+		rec.hit = -2;
+	if (rec.hit == -1) {
+		const uint32_t r0 = cv.rdp_off[r], r1 = cv.rdp_off[r + 1];
+		uint32_t maxrm = 0, maxcnt = 0, cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+		for (uint32_t k = 0; k < n; k++) {
+			const pgx_hit h = hits[o + k];
+			uint32_t c;
+			const uint32_t rm = rank_matches(cv, (uint32_t)h.subject, r0, r1, &c);
+			const int len = h.qend - h.qstart + 1;
+			const uint32_t sim = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
+			if (dec_str_gt(rm, maxrm)) {
+				maxrm = rm;
+				rec.hit = (int32_t)(o + k);
+				cursim = sim;
+			}
+			if ((dec_str_gt(c, maxcnt) || cursim < sim) && rm == maxrm) {
+				maxcnt = c;
+				rec.hit = (int32_t)(o + k);
+				cursim = sim;
+			}
+		}
+		rec.matches = (int32_t)maxrm;
+	}
+	recs[r] = rec;
+}
+
+// ------------------------------------------------------------------------------------------ host drivers
+static pgx_stage_times g_times;
+
+static DbView db_view(const pgx_db *db)
+{
+	DbView v;
+	v.words = db->d_words.data();
+	v.amb = db->has_amb ? db->d_amb.data() : nullptr;
+	v.seq_off = db->d_seq_off.data();
+	v.blk_subj = db->d_blk_subj.data();
+	v.bucket_off = db->d_bucket_off.data();
+	v.postings = db->d_postings.data();
+	v.n_seq = (uint32_t)db->n_seq;
+	v.bits = db->index_bits;
+	return v;
+}
+
+static ReadsView reads_view(const pgx_reads *rd)
+{
+	ReadsView v;
+	v.fwd = rd->d_fwd.data();
+	v.rc = rd->d_rc.data();
+	v.fwd_amb = rd->has_amb ? rd->d_fwd_amb.data() : nullptr;
+	v.rc_amb = rd->has_amb ? rd->d_rc_amb.data() : nullptr;
+	v.len = rd->d_len.data();
+	v.woff = rd->d_woff.data();
+	v.n = (uint32_t)rd->n;
+	return v;
+}
+
+static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
+{
+	ConsView cv;
+	memset(&cv, 0, sizeof cv);
+	if (db && db->bound) {
+		cv.subj_tok_off = db->d_subj_tok_off.data();
+		cv.subj_tok = db->d_subj_tok.data();
+		cv.tok_rank = db->d_tok_rank.data();
+		cv.simrank_lut = db->d_simrank_lut.data();
+		cv.simrank_undef = db->simrank_undef;
+		cv.simrank_zero = db->simrank_zero;
+	}
+	if (rdp) {
+		cv.rdp_off = rdp->d_off.data();
+		cv.rdp_name = rdp->d_name.data();
+		cv.rdp_rank = rdp->d_rank.data();
+		cv.rdp_present = rdp->d_present.data();
+	}
+	return cv;
+}
+
+struct EventTimer {
+	hipEvent_t a = nullptr, b = nullptr;
+	EventTimer()
+	{
+		(void)hipEventCreate(&a);
+		(void)hipEventCreate(&b);
+	}
+	~EventTimer()
+	{
+		(void)hipEventDestroy(a);
+		(void)hipEventDestroy(b);
+	}
+	void start() { (void)hipEventRecord(a, 0); }
+	float stop()
+	{
+		(void)hipEventRecord(b, 0);
+		(void)hipEventSynchronize(b);
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, a, b);
+		return ms;
+	}
+};
+
+// search + group + sort (+ consensus when rdp != null). d_recs: device array of n_reads records.
+int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out, pgx_consensus_rec *d_recs)
+{
+	PGX_TRY(require_device());
+	if (rdp && !db->bound)
+		return fail(PGX_E_ARG, "consensus needs pgx_db_bind_taxonomy() first");
+	if (rdp && rdp->n != rd->n)
+		return fail(PGX_E_ARG, "RDP stream holds %lld reads, batch holds %lld", (long long)rdp->n, (long long)rd->n);
+	memset(&g_times, 0, sizeof g_times);
+	const uint64_t n = (uint64_t)rd->n;
+	out->n_reads = rd->n;
+	PGX_TRY(out->d_read_cnt.alloc(n + 1, 0, 0, true));
+	PGX_TRY(out->d_read_off.alloc(n + 1, 0, 0, true));
+	DevBuf<unsigned long long> counters;
+	PGX_TRY(counters.alloc(4, 0, 0, true));
+	if (n == 0) {
+		out->n_hits = 0;
+		return 0;
+	}
+	const DbView dv = db_view(db);
+	const ReadsView rv = reads_view(rd);
+	const bool amb = db->has_amb || rd->has_amb;
+	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
+	EventTimer total, t;
+	total.start();
+
+	// seed + extend into a scratch table; grow and repeat if the guess was too small
+	uint64_t cap = std::max<uint64_t>(n * 48, 1 << 16);
+	DevBuf<pgx_hit> scratch;
+	unsigned long long h_cnt[4];
+	for (;;) {
+		PGX_TRY(scratch.alloc(cap));
+		PGX_HIP(hipMemsetAsync(counters.data(), 0, 4 * sizeof(unsigned long long), 0));
+		t.start();
+		if (amb)
+			hipLaunchKernelGGL(k_seed_extend<true>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, dv, rv,
+					   scratch.data(), (unsigned long long)cap, counters.data(), out->d_read_cnt.data());
+		else
+			hipLaunchKernelGGL(k_seed_extend<false>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, dv, rv,
+					   scratch.data(), (unsigned long long)cap, counters.data(), out->d_read_cnt.data());
+		PGX_HIP(hipGetLastError());
+		g_times.seed_extend_ms = t.stop();
+		PGX_TRY(counters.download(h_cnt, 4));
+		if (h_cnt[0] <= cap)
+			break;
+		cap = h_cnt[0] + h_cnt[0] / 8;
+	}
+	const uint64_t H = h_cnt[0];
+	out->n_hits = (int64_t)H;
+	g_times.hits = (int64_t)H;
+	g_times.probes = (int64_t)h_cnt[1];
+	g_times.postings = (int64_t)h_cnt[2];
+	if (H >= (1ull << 32))
+		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
+			    (unsigned long long)H);
+
+	// group by read: exclusive scan of the per-read counts, then scatter
+	t.start();
+	const uint32_t n_part = (uint32_t)((n + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
+	DevBuf<uint32_t> partial, cursor;
+	PGX_TRY(partial.alloc(n_part));
+	PGX_TRY(cursor.alloc(n, 0, 0, true));
+	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data());
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, 0, partial.data(), n_part);
+	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data(),
+			   out->d_read_off.data());
+	PGX_HIP(hipGetLastError());
+	PGX_TRY(out->d_hits.alloc(H ? H : 1));
+	if (H) {
+		const int g2 = (int)std::min<uint64_t>((H + 255) / 256, 256ull * 16);
+		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, scratch.data(), H, out->d_read_off.data(),
+				   cursor.data(), out->d_hits.data());
+		PGX_HIP(hipGetLastError());
+	}
+	g_times.group_ms = t.stop();
+
+	// per-read order (+ consensus)
+	t.start();
+	DevBuf<uint32_t> big_list, big_count;
+	PGX_TRY(big_list.alloc(n));
+	PGX_TRY(big_count.alloc(1, 0, 0, true));
+	const ConsView cv = cons_view(db, rdp);
+	const size_t lds = sizeof(SortWave) * kWavesPerBlock;
+	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), lds, 0, out->d_hits.data(),
+			   out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, d_recs,
+			   big_list.data(), big_count.data());
+	PGX_HIP(hipGetLastError());
+	uint32_t n_big = 0;
+	PGX_TRY(big_count.download(&n_big, 1));
+	if (n_big) {
+		DevBuf<int> best_ws;
+		PGX_TRY(best_ws.alloc(H));
+		// the scratch table still holds nothing we need: reuse it as the destination, then copy back
+		PGX_HIP(hipMemcpyAsync(scratch.data(), out->d_hits.data(), H * sizeof(pgx_hit), hipMemcpyDeviceToDevice, 0));
+		hipLaunchKernelGGL(k_sort_big, dim3(std::min<uint32_t>(n_big, 4096)), dim3(256), 0, 0, scratch.data(),
+				   out->d_hits.data(), out->d_read_off.data(), out->d_read_cnt.data(), big_list.data(), n_big,
+				   best_ws.data());
+		PGX_HIP(hipGetLastError());
+		if (rdp) {
+			hipLaunchKernelGGL(k_consensus_serial, dim3((n_big + 63) / 64), dim3(64), 0, 0, out->d_hits.data(),
+					   out->d_read_off.data(), out->d_read_cnt.data(), big_list.data(), n_big, cv, d_recs);
+			PGX_HIP(hipGetLastError());
+		}
+	}
+	g_times.sort_ms = t.stop();
+	g_times.total_ms = total.stop();
+	return 0;
+}
+
+} // namespace pgx
+
+using namespace pgx;
+
+extern "C" {
+
+int pgx_blast_search(pgx_db *db, pgx_reads *reads, pgx_hits **out)
+{
+	if (!db || !reads || !out)
+		return fail(PGX_E_ARG, "pgx_blast_search: null argument");
+	pgx_hits *h = new pgx_hits();
+	int rc = search_pipeline(db, reads, nullptr, h, nullptr);
+	if (rc < 0) {
+		delete h;
+		return rc;
+	}
+	*out = h;
+	return 0;
+}
+
+int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx_hits **hits_out, pgx_consensus_rec *out,
+			   int64_t cap)
+{
+	if (!db || !reads || !rdp)
+		return fail(PGX_E_ARG, "pgx_classify_consensus: null argument");
+	DevBuf<pgx_consensus_rec> recs;
+	PGX_TRY(recs.alloc((size_t)reads->n + 1));
+	pgx_hits *h = new pgx_hits();
+	int rc = search_pipeline(db, reads, rdp, h, recs.data());
+	if (rc == 0 && out) {
+		if (cap < reads->n)
+			rc = fail(PGX_E_ARG, "record buffer too small");
+		else
+			rc = recs.download(out, (size_t)reads->n);
+	}
+	if (rc < 0 || !hits_out)
+		delete h;
+	else
+		*hits_out = h;
+	return rc;
+}
+
+void pgx_hits_close(pgx_hits *h) { delete h; }
+int64_t pgx_hits_count(const pgx_hits *h) { return h ? h->n_hits : 0; }
+
+int pgx_hits_copy(const pgx_hits *h, pgx_hit *out, int64_t cap)
+{
+	if (!h || !out || cap < h->n_hits)
+		return fail(PGX_E_ARG, "pgx_hits_copy: bad argument");
+	return h->d_hits.download(out, (size_t)h->n_hits);
+}
+
+int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap)
+{
+	if (!h || !out || cap < h->n_reads + 1)
+		return fail(PGX_E_ARG, "pgx_hits_read_offsets: bad argument");
+	std::vector<uint32_t> tmp((size_t)h->n_reads + 1);
+	PGX_TRY(h->d_read_off.download(tmp.data(), tmp.size()));
+	for (size_t i = 0; i < tmp.size(); i++)
+		out[i] = tmp[i];
+	return 0;
+}
+
+int pgx_last_stage_times(pgx_stage_times *out)
+{
+	if (!out)
+		return fail(PGX_E_ARG, "pgx_last_stage_times: null argument");
+	*out = g_times;
+	return 0;
+}
+}

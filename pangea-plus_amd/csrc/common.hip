@@ -1,0 +1,143 @@
+// Status/error text, device selection, small host utilities.
+#include "common.hpp"
+
+namespace pgx {
+
+static thread_local char g_err[1024] = "";
+static int g_device = -1;
+
+void set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+const char *get_error() { return g_err; }
+
+int fail(int status, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return status;
+}
+
+int require_device()
+{
+	if (g_device >= 0)
+		return 0;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(PGX_E_NODEVICE,
+			    "no HIP device: libpangea_hip has no CPU path (hipGetDeviceCount: %s, %d devices)",
+			    hipGetErrorString(e), n);
+	e = hipSetDevice(0);
+	if (e != hipSuccess)
+		return fail(PGX_E_NODEVICE, "hipSetDevice(0) failed: %s", hipGetErrorString(e));
+	g_device = 0;
+	return 0;
+}
+
+void Text::printf(const char *fmt, ...)
+{
+	char small[512];
+	va_list ap, ap2;
+	va_start(ap, fmt);
+	va_copy(ap2, ap);
+	int need = vsnprintf(small, sizeof small, fmt, ap);
+	va_end(ap);
+	if (need < 0) {
+		va_end(ap2);
+		return;
+	}
+	if ((size_t)need < sizeof small) {
+		s.append(small, (size_t)need);
+	} else {
+		size_t old = s.size();
+		s.resize(old + (size_t)need + 1);
+		vsnprintf(&s[old], (size_t)need + 1, fmt, ap2);
+		s.resize(old + (size_t)need);
+	}
+	va_end(ap2);
+}
+
+char *Text::release_malloc(size_t *len) const
+{
+	char *p = (char *)malloc(s.size() + 1);
+	if (!p)
+		return nullptr;
+	memcpy(p, s.data(), s.size());
+	p[s.size()] = '\0';
+	if (len)
+		*len = s.size();
+	return p;
+}
+
+std::string read_text_file(const char *path, bool *ok)
+{
+	std::string out;
+	FILE *f = fopen(path, "rb");
+	if (!f) {
+		*ok = false;
+		return out;
+	}
+	char buf[1 << 16];
+	size_t n;
+	while ((n = fread(buf, 1, sizeof buf, f)) > 0)
+		out.append(buf, n);
+	fclose(f);
+	*ok = true;
+	return out;
+}
+
+int write_text_file(const char *path, const std::string &s)
+{
+	FILE *f = fopen(path, "wb");
+	if (!f)
+		return fail(PGX_E_IO, "cannot open %s for writing", path);
+	if (!s.empty() && fwrite(s.data(), 1, s.size(), f) != s.size()) {
+		fclose(f);
+		return fail(PGX_E_IO, "short write to %s", path);
+	}
+	if (fclose(f))
+		return fail(PGX_E_IO, "close of %s failed", path);
+	return 0;
+}
+
+} // namespace pgx
+
+extern "C" {
+
+const char *pgx_last_error(void) { return pgx::get_error(); }
+const char *pgx_version(void) { return "pangea_hip 0.1 (gfx950; pgx-blastn v1)"; }
+
+int pgx_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int pgx_init(int device)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return pgx::fail(PGX_E_NODEVICE, "no HIP device: libpangea_hip has no CPU path (%s)",
+				 hipGetErrorString(e));
+	if (device < 0 || device >= n)
+		return pgx::fail(PGX_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+	e = hipSetDevice(device);
+	if (e != hipSuccess)
+		return pgx::fail(PGX_E_NODEVICE, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+	pgx::g_device = device;
+	return 0;
+}
+
+void pgx_free(void *p) { free(p); }
+}

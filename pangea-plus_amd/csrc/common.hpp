@@ -1,0 +1,110 @@
+// Shared plumbing of libpangea_hip: status/error text, HIP call checking, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pangea_hip.h"
+
+namespace pgx {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *get_error();
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Every compute entry point goes through this first: the product has no CPU path.
+int require_device();
+
+#define PGX_HIP(call)                                                                              \
+	do {                                                                                       \
+		hipError_t e_ = (call);                                                            \
+		if (e_ != hipSuccess)                                                              \
+			return ::pgx::fail(PGX_E_NODEVICE, "%s failed: %s (%s:%d)", #call,         \
+					   hipGetErrorString(e_), __FILE__, __LINE__);             \
+	} while (0)
+
+#define PGX_TRY(expr)                                                                              \
+	do {                                                                                       \
+		int rc_ = (expr);                                                                  \
+		if (rc_ < 0)                                                                       \
+			return rc_;                                                                \
+	} while (0)
+
+// Owning device allocation. `front_pad` elements are kept in front of data() so that kernels
+// may read a little before the first element (diagonals that start left of the database).
+template <typename T> struct DevBuf {
+	T *base = nullptr;
+	size_t n = 0, pad = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { release(); }
+	void release()
+	{
+		if (base)
+			(void)hipFree(base);
+		base = nullptr;
+		n = pad = 0;
+	}
+	int alloc(size_t count, size_t front_pad = 0, size_t back_pad = 0, bool zero = false)
+	{
+		release();
+		size_t total = count + front_pad + back_pad;
+		if (total == 0)
+			total = 1;
+		hipError_t e = hipMalloc((void **)&base, total * sizeof(T));
+		if (e != hipSuccess) {
+			base = nullptr;
+			return fail(PGX_E_NOMEM, "hipMalloc of %zu bytes failed: %s", total * sizeof(T),
+				    hipGetErrorString(e));
+		}
+		n = count;
+		pad = front_pad;
+		if (zero || front_pad || back_pad) {
+			e = hipMemset(base, 0, total * sizeof(T));
+			if (e != hipSuccess)
+				return fail(PGX_E_NODEVICE, "hipMemset failed: %s", hipGetErrorString(e));
+		}
+		return 0;
+	}
+	T *data() const { return base ? base + pad : nullptr; }
+	size_t bytes() const { return n * sizeof(T); }
+	int upload(const T *host, size_t count)
+	{
+		if (count > n)
+			return fail(PGX_E_ARG, "upload larger than buffer");
+		if (count == 0)
+			return 0;
+		hipError_t e = hipMemcpy(data(), host, count * sizeof(T), hipMemcpyHostToDevice);
+		if (e != hipSuccess)
+			return fail(PGX_E_NODEVICE, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+	int download(T *host, size_t count, size_t first = 0) const
+	{
+		if (count == 0)
+			return 0;
+		hipError_t e = hipMemcpy(host, data() + first, count * sizeof(T), hipMemcpyDeviceToHost);
+		if (e != hipSuccess)
+			return fail(PGX_E_NODEVICE, "hipMemcpy D2H failed: %s", hipGetErrorString(e));
+		return 0;
+	}
+};
+
+// growable text buffer for the formatters
+struct Text {
+	std::string s;
+	void printf(const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+	char *release_malloc(size_t *len) const;
+};
+
+std::string read_text_file(const char *path, bool *ok);
+int write_text_file(const char *path, const std::string &s);
+
+} // namespace pgx

@@ -1,0 +1,114 @@
+// Internal object model of libpangea_hip: what lives in HBM for one process / one GPU.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// Sequence database in HBM.
+//   d_words     2-bit packed bases of all sequences back to back (1 zero word in front, 2 behind)
+//   d_amb       optional spaced ambiguity flags, same geometry (absent when the DB is pure ACGT)
+//   d_seq_off   n_seq+1 base offsets;  d_blk_subj[b] = subject holding base 64*b
+//   seed index  every 16-mer start position of the concatenation, grouped by
+//               seed_bucket(kmer, index_bits):  d_bucket_off[2^bits + 1], d_postings[n_postings]
+//               (ascending position inside a bucket).  At 1 Gbp: bits = 32 (17.2 GB of offsets +
+//               4 GB of postings — sized for 288 GB of HBM, one dependent gather per probe).
+// ---------------------------------------------------------------------------------------------
+struct pgx_db {
+	int64_t n_seq = 0, n_bases = 0;
+	bool has_amb = false;
+	std::vector<uint32_t> h_seq_off;
+	std::vector<std::string> ids;
+	// host copy of the packed bases is kept only for file-built databases (SOAP row formatting)
+	std::vector<uint64_t> h_words, h_amb;
+
+	pgx::DevBuf<uint64_t> d_words, d_amb;
+	pgx::DevBuf<uint32_t> d_seq_off, d_blk_subj;
+	int index_bits = 0;
+	int64_t n_postings = 0;
+	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
+
+	// taxonomy binding (pgx_db_bind_taxonomy): per subject lineage text + consensus tokens
+	bool bound = false;
+	std::vector<std::string> lineage;            // per subject, taxcollector text
+	std::vector<std::string> token_text;         // token id -> text (id 0 = "")
+	std::unordered_map<std::string, uint32_t> token_id;
+	pgx::DevBuf<uint32_t> d_subj_tok_off, d_subj_tok; // CSR of token ids per subject
+	pgx::DevBuf<int8_t> d_tok_rank;                   // token id -> index in "0".."6" or -1
+	std::vector<int8_t> h_tok_rank;
+	std::vector<int32_t> subj_taxid;
+	pgx::DevBuf<uint32_t> d_node_name_tok;       // taxid -> token id of a one-word scientific name (else 0)
+	pgx::DevBuf<uint32_t> d_simrank_lut;         // pident hundredths -> string-order rank
+	uint32_t simrank_undef = 0, simrank_zero = 0;
+	uint32_t intern(const std::string &s);
+};
+
+// A batch of reads in HBM: forward and reverse-complement strands, each read word-aligned.
+struct pgx_reads {
+	int64_t n = 0;
+	int64_t first = 0; // ordinal of read 0 within its source (names r<first+i> for synthetic reads)
+	bool synthetic = false;
+	bool has_amb = false;
+	std::vector<std::string> names; // empty for synthetic batches
+	std::vector<uint32_t> h_len, h_woff;
+	int64_t n_words = 0;
+	int32_t max_len = 0;
+	pgx::DevBuf<uint64_t> d_fwd, d_rc, d_fwd_amb, d_rc_amb;
+	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
+	std::string name_of(int64_t i) const;
+};
+
+struct pgx_hits {
+	int64_t n_reads = 0;
+	int64_t n_hits = 0; // slots in d_hits (including hits dropped by the 500-subject limit)
+	pgx::DevBuf<pgx_hit> d_hits;     // grouped by read, spec order inside a read
+	pgx::DevBuf<uint32_t> d_read_off; // n_reads+1 slot offsets
+	pgx::DevBuf<uint32_t> d_read_cnt; // hits kept per read (<= slots of the read)
+};
+
+struct pgx_rdp {
+	int64_t n = 0;
+	pgx::DevBuf<uint32_t> d_off;   // n+1, in triplets
+	pgx::DevBuf<uint32_t> d_name;  // token id of the cleaned name
+	pgx::DevBuf<int8_t> d_rank;    // index in (domain..species) or -1
+	pgx::DevBuf<uint8_t> d_present; // 0: read has no RDP line (never selected)
+};
+
+namespace pgx {
+
+// seqdb.hip
+int db_upload_and_index(pgx_db *db);
+int db_build_index(pgx_db *db);
+int choose_index_bits(int64_t n_postings);
+
+// classify.hip
+struct SearchCounters {
+	unsigned long long probes, postings, candidates, hits;
+};
+int blast_search_device(pgx_db *db, pgx_reads *reads, pgx_hits *out, pgx_stage_times *times);
+int consensus_device(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *d_out,
+		     pgx_stage_times *times);
+
+// pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
+__host__ __device__ inline int pident_hundredths(int matches, int length)
+{
+	long long num = 10000ll * matches;
+	long long q = num / length, r = num % length;
+	if (2 * r > length)
+		return (int)(q + 1);
+	if (2 * r < length)
+		return (int)q;
+	// exact rational tie: printf rounds the binary value d = 100.0*m/L, which may sit on either
+	// side of it; fma gives the sign of d*200 - (2q+1) exactly
+	double d = 100.0 * (double)matches / (double)length;
+	double s = fma(d, 200.0, -(double)(2 * q + 1));
+	if (s > 0)
+		return (int)(q + 1);
+	if (s < 0)
+		return (int)q;
+	return (int)(q + (q & 1));
+}
+
+} // namespace pgx

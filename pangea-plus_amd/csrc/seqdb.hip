@@ -1,0 +1,774 @@
+// Sequence database and read batches: FASTA -> 2-bit packing, the .pgxdb file, upload to HBM,
+// the device-built 16-mer seed index, and the synthetic workload generator kernels.
+//
+// Replaces `makeblastdb -in nt -out nt -dbtype nucl` (reference README.md:62) and
+// `2bwt-builder ref.fasta` (README.md:130); both reference tools are external/closed, the
+// format here is the build's own.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+
+#include "bitops.hpp"
+#include "engine.hpp"
+
+namespace pgx {
+
+// ------------------------------------------------------------------------------------------ host packing
+static inline int base_code(unsigned char c)
+{
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': case 'U': case 'u': return 3;
+	default: return 4;
+	}
+}
+
+struct PackedSet {
+	std::vector<std::string> headers;
+	std::vector<uint64_t> off; // n+1 base offsets (back to back)
+	std::vector<uint64_t> words, amb;
+	bool any_amb = false;
+};
+
+// Sequences packed back to back (database layout).
+static int pack_fasta_text(const std::string &text, PackedSet &ps)
+{
+	ps.off.push_back(0);
+	uint64_t total = 0;
+	bool in_seq = false;
+	size_t i = 0, n = text.size();
+	ps.words.reserve(n / 32 + 4);
+	auto put = [&](int code) {
+		size_t w = total >> 5;
+		if (w >= ps.words.size()) {
+			ps.words.push_back(0);
+			ps.amb.push_back(0);
+		}
+		int sh = (int)(total & 31) * 2;
+		if (code < 4) {
+			ps.words[w] |= (uint64_t)code << sh;
+		} else {
+			ps.amb[w] |= 1ull << sh;
+			ps.any_amb = true;
+		}
+		total++;
+	};
+	while (i < n) {
+		size_t e = text.find('\n', i);
+		if (e == std::string::npos)
+			e = n;
+		size_t ll = e - i;
+		if (ll && text[i + ll - 1] == '\r')
+			ll--;
+		if (ll && text[i] == '>') {
+			if (in_seq)
+				ps.off.push_back(total);
+			ps.headers.emplace_back(text, i + 1, ll - 1);
+			in_seq = true;
+		} else if (in_seq) {
+			for (size_t k = 0; k < ll; k++) {
+				unsigned char c = (unsigned char)text[i + k];
+				if (c == ' ' || c == '\t')
+					continue;
+				put(base_code(c));
+			}
+		}
+		i = e + 1;
+	}
+	if (in_seq)
+		ps.off.push_back(total);
+	return 0;
+}
+
+static std::string first_word(const std::string &h)
+{
+	size_t k = 0;
+	while (k < h.size() && h[k] != ' ' && h[k] != '\t')
+		k++;
+	return h.substr(0, k);
+}
+
+int choose_index_bits(int64_t n_postings)
+{
+	int lg = 0;
+	while (lg < 62 && (1ll << lg) < n_postings)
+		lg++;
+	int b = lg + 2;
+	if (b < 16)
+		b = 16;
+	if (b > 32)
+		b = 32;
+	return b;
+}
+
+// ------------------------------------------------------------------------------------------ device: index build
+__global__ void k_blk_subj(const uint32_t *__restrict__ seq_off, uint32_t n_seq, uint32_t *__restrict__ blk,
+			   uint64_t n_blk)
+{
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blk)
+		return;
+	uint64_t p = b * 64;
+	uint32_t lo = 0, hi = n_seq; // last subject with seq_off <= p
+	while (hi - lo > 1) {
+		uint32_t mid = lo + (hi - lo) / 2;
+		if (seq_off[mid] <= p)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	blk[b] = lo;
+}
+
+__global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, int bits, uint32_t *__restrict__ keys,
+			    uint32_t *__restrict__ vals)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n_pos; i += stride) {
+		keys[i] = seed_bucket(kmer16(words, (int64_t)i), bits);
+		vals[i] = (uint32_t)i;
+	}
+}
+
+// run heads of the sorted keys write the run length into counts[key]
+__global__ void k_bucket_counts(const uint32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ counts)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		uint32_t k = keys[i];
+		if (i > 0 && keys[i - 1] == k)
+			continue;
+		// end of the run: short linear probe (most buckets hold a few postings), then bisect
+		uint64_t lo = i;
+		int c = 0;
+		while (lo + 1 < n && c < 32 && keys[lo + 1] == k) {
+			lo++;
+			c++;
+		}
+		if (lo + 1 < n && keys[lo + 1] == k) {
+			uint64_t hi = n; // keys[lo] == k, first index with a larger key is in (lo, hi]
+			while (hi - lo > 1) {
+				uint64_t mid = lo + (hi - lo) / 2;
+				if (keys[mid] == k)
+					lo = mid;
+				else
+					hi = mid;
+			}
+		}
+		counts[k] = (uint32_t)(lo + 1 - i);
+	}
+}
+
+int db_build_index(pgx_db *db)
+{
+	db->n_postings = db->n_bases >= kSeedK ? db->n_bases - kSeedK + 1 : 0;
+	db->index_bits = choose_index_bits(db->n_postings);
+	const uint64_t n = (uint64_t)db->n_postings;
+	const uint64_t nb = 1ull << db->index_bits;
+	PGX_TRY(db->d_bucket_off.alloc(nb + 1, 0, 0, true));
+	PGX_TRY(db->d_postings.alloc(n ? n : 1));
+	if (n == 0)
+		return 0;
+	DevBuf<uint32_t> keys_in, keys_out, vals_in;
+	PGX_TRY(keys_in.alloc(n));
+	PGX_TRY(keys_out.alloc(n));
+	PGX_TRY(vals_in.alloc(n));
+	int grid = (int)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+	hipLaunchKernelGGL(k_seed_keys, dim3(grid), dim3(256), 0, 0, db->d_words.data(), n, db->index_bits,
+			   keys_in.data(), vals_in.data());
+	PGX_HIP(hipGetLastError());
+	size_t tmp_bytes = 0;
+	PGX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.data(), keys_out.data(), vals_in.data(),
+					  db->d_postings.data(), n, 0, db->index_bits));
+	DevBuf<uint8_t> tmp;
+	PGX_TRY(tmp.alloc(tmp_bytes));
+	PGX_HIP(rocprim::radix_sort_pairs(tmp.data(), tmp_bytes, keys_in.data(), keys_out.data(), vals_in.data(),
+					  db->d_postings.data(), n, 0, db->index_bits));
+	hipLaunchKernelGGL(k_bucket_counts, dim3(grid), dim3(256), 0, 0, keys_out.data(), n, db->d_bucket_off.data());
+	PGX_HIP(hipGetLastError());
+	keys_in.release();
+	vals_in.release();
+	// exclusive scan of the counts in place -> bucket offsets; the extra last element becomes n
+	size_t scan_bytes = 0;
+	PGX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, db->d_bucket_off.data(), db->d_bucket_off.data(), 0u,
+					nb + 1, rocprim::plus<uint32_t>()));
+	DevBuf<uint8_t> tmp2;
+	PGX_TRY(tmp2.alloc(scan_bytes));
+	PGX_HIP(rocprim::exclusive_scan(tmp2.data(), scan_bytes, db->d_bucket_off.data(), db->d_bucket_off.data(), 0u,
+					nb + 1, rocprim::plus<uint32_t>()));
+	PGX_HIP(hipDeviceSynchronize());
+	return 0;
+}
+
+static int db_upload_offsets(pgx_db *db)
+{
+	PGX_TRY(db->d_seq_off.alloc((size_t)db->n_seq + 1));
+	PGX_TRY(db->d_seq_off.upload(db->h_seq_off.data(), (size_t)db->n_seq + 1));
+	uint64_t n_blk = ((uint64_t)db->n_bases + 63) / 64 + 1;
+	PGX_TRY(db->d_blk_subj.alloc(n_blk));
+	if (db->n_seq > 0) {
+		hipLaunchKernelGGL(k_blk_subj, dim3((unsigned)((n_blk + 255) / 256)), dim3(256), 0, 0,
+				   db->d_seq_off.data(), (uint32_t)db->n_seq, db->d_blk_subj.data(), n_blk);
+		PGX_HIP(hipGetLastError());
+	}
+	return 0;
+}
+
+int db_upload_and_index(pgx_db *db)
+{
+	PGX_TRY(require_device());
+	if (db->n_bases >= (1ll << 32) - 64)
+		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 32-bit position limit of this build",
+			    (long long)db->n_bases);
+	size_t nw = ((size_t)db->n_bases + 31) / 32;
+	PGX_TRY(db->d_words.alloc(nw, 1, 2, true));
+	PGX_TRY(db->d_words.upload(db->h_words.data(), std::min(nw, db->h_words.size())));
+	if (db->has_amb) {
+		PGX_TRY(db->d_amb.alloc(nw, 1, 2, true));
+		PGX_TRY(db->d_amb.upload(db->h_amb.data(), std::min(nw, db->h_amb.size())));
+	}
+	PGX_TRY(db_upload_offsets(db));
+	return db_build_index(db);
+}
+
+static int db_from_packed(PackedSet &ps, pgx_db **out)
+{
+	pgx_db *db = new pgx_db();
+	db->n_seq = (int64_t)ps.headers.size();
+	db->n_bases = (int64_t)ps.off.back();
+	db->has_amb = ps.any_amb;
+	db->h_seq_off.resize(ps.off.size());
+	for (size_t i = 0; i < ps.off.size(); i++)
+		db->h_seq_off[i] = (uint32_t)ps.off[i];
+	for (auto &h : ps.headers)
+		db->ids.push_back(first_word(h));
+	db->h_words.swap(ps.words);
+	db->h_amb.swap(ps.amb);
+	*out = db;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------ .pgxdb file
+static const char kMagic[8] = { 'P', 'G', 'X', 'D', 'B', '1', 0, 0 };
+
+static int db_write_file(const pgx_db *db, const char *prefix)
+{
+	std::string path = std::string(prefix) + ".pgxdb";
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f)
+		return fail(PGX_E_IO, "cannot open %s for writing", path.c_str());
+	int64_t hdr[4] = { db->n_seq, db->n_bases, db->has_amb ? 1 : 0, (int64_t)db->h_words.size() };
+	bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof hdr, 1, f) == 1;
+	ok = ok && fwrite(db->h_seq_off.data(), 4, db->h_seq_off.size(), f) == db->h_seq_off.size();
+	ok = ok && (db->h_words.empty() || fwrite(db->h_words.data(), 8, db->h_words.size(), f) == db->h_words.size());
+	if (db->has_amb)
+		ok = ok && fwrite(db->h_amb.data(), 8, db->h_amb.size(), f) == db->h_amb.size();
+	for (auto &id : db->ids) {
+		uint32_t l = (uint32_t)id.size();
+		ok = ok && fwrite(&l, 4, 1, f) == 1 && (l == 0 || fwrite(id.data(), 1, l, f) == l);
+	}
+	if (fclose(f) || !ok)
+		return fail(PGX_E_IO, "short write to %s", path.c_str());
+	return 0;
+}
+
+static int db_read_file(const char *prefix, pgx_db **out)
+{
+	std::string path = std::string(prefix) + ".pgxdb";
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f)
+		return fail(PGX_E_IO, "cannot open database %s", path.c_str());
+	char magic[8];
+	int64_t hdr[4];
+	if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, sizeof hdr, 1, f) != 1) {
+		fclose(f);
+		return fail(PGX_E_FORMAT, "%s is not a pgxdb file", path.c_str());
+	}
+	pgx_db *db = new pgx_db();
+	db->n_seq = hdr[0];
+	db->n_bases = hdr[1];
+	db->has_amb = hdr[2] != 0;
+	db->h_seq_off.resize((size_t)db->n_seq + 1);
+	db->h_words.resize((size_t)hdr[3]);
+	bool ok = fread(db->h_seq_off.data(), 4, db->h_seq_off.size(), f) == db->h_seq_off.size();
+	ok = ok && (db->h_words.empty() || fread(db->h_words.data(), 8, db->h_words.size(), f) == db->h_words.size());
+	if (db->has_amb) {
+		db->h_amb.resize((size_t)hdr[3]);
+		ok = ok && fread(db->h_amb.data(), 8, db->h_amb.size(), f) == db->h_amb.size();
+	}
+	for (int64_t i = 0; ok && i < db->n_seq; i++) {
+		uint32_t l;
+		ok = fread(&l, 4, 1, f) == 1 && l < (1u << 20);
+		std::string id(ok ? l : 0, '\0');
+		ok = ok && (l == 0 || fread(&id[0], 1, l, f) == l);
+		db->ids.push_back(id);
+	}
+	fclose(f);
+	if (!ok) {
+		delete db;
+		return fail(PGX_E_FORMAT, "%s is truncated", path.c_str());
+	}
+	*out = db;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------ synthetic DB on device
+__device__ __forceinline__ uint32_t synth_db_base(uint64_t seed, uint64_t i, uint64_t g, uint32_t j)
+{
+	uint64_t a = synth_hash(seed, 1, g, j >> 5);
+	uint32_t b = (uint32_t)(a >> (2 * (j & 31))) & 3;
+	uint64_t m = synth_hash(seed, 2, i, j >> 2);
+	uint32_t f = (uint32_t)(m >> (16 * (j & 3))) & 0xFFFF;
+	if (f < 1966)
+		b = (b + 1 + f % 3) & 3;
+	return b;
+}
+
+// one thread per output word (32 bases); sequences are back to back, so a word may straddle two
+__global__ void k_synth_db(uint64_t seed, uint64_t n_seq, uint32_t seq_len, uint64_t n_genus,
+			   uint64_t *__restrict__ words, uint64_t n_words, uint64_t n_bases)
+{
+	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words)
+		return;
+	uint64_t out = 0;
+	uint64_t p0 = w * 32;
+	for (int k = 0; k < 32; k++) {
+		uint64_t p = p0 + k;
+		if (p >= n_bases)
+			break;
+		uint64_t i = p / seq_len;
+		uint32_t j = (uint32_t)(p - i * seq_len);
+		uint64_t g = (uint64_t)(((unsigned __int128)i * n_genus) / n_seq);
+		out |= (uint64_t)synth_db_base(seed, i, g, j) << (2 * k);
+	}
+	words[w] = out;
+}
+
+// ------------------------------------------------------------------------------------------ reads
+// reverse complement of every read, one thread per output word
+__global__ void k_revcomp(const uint64_t *__restrict__ fwd, const uint32_t *__restrict__ woff,
+			  const uint32_t *__restrict__ len, uint64_t n_reads, uint64_t *__restrict__ rc, int is_mask)
+{
+	uint64_t r = (uint64_t)blockIdx.x;
+	for (; r < n_reads; r += gridDim.x) {
+		uint32_t L = len[r], w0 = woff[r], nw = (L + 31) / 32;
+		for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+			// rc bases [32w, 32w+32) = forward bases [L-32w-32, L-32w) reversed
+			int64_t s = (int64_t)L - 32 * (int64_t)w - 32;
+			uint64_t x;
+			if (s >= 0) {
+				int64_t wi = s >> 5;
+				int sh = (int)(s & 31) * 2;
+				uint64_t lo = fwd[w0 + wi];
+				uint64_t hi = (sh && wi + 1 < nw) ? fwd[w0 + wi + 1] : 0;
+				x = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+			} else {
+				// fewer than 32 forward bases remain: they are bases [0, 32+s)
+				x = fwd[w0] << (2 * (int)(-s));
+			}
+			uint64_t y = reverse_groups(x);
+			int valid = (int)((int64_t)L - 32 * (int64_t)w);
+			if (valid > 32)
+				valid = 32;
+			uint64_t keep = valid >= 32 ? ~0ull : ((1ull << (2 * valid)) - 1);
+			if (!is_mask)
+				y = ~y;
+			rc[w0 + w] = y & keep;
+		}
+	}
+}
+
+__global__ void k_synth_reads(uint64_t seed, uint64_t n_seq, uint32_t seq_len, uint64_t n_genus, uint64_t read_seed,
+			      uint32_t read_len, uint64_t first, uint64_t count, uint32_t words_per_read,
+			      uint64_t *__restrict__ fwd)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= count * words_per_read)
+		return;
+	uint64_t ri = t / words_per_read;
+	uint32_t w = (uint32_t)(t - ri * words_per_read);
+	uint64_t r = first + ri;
+	uint64_t u = synth_hash(read_seed, 3, r, 0);
+	uint64_t i = (u & 0xFFFFFFFFull) % n_seq;
+	uint32_t off = (uint32_t)((u >> 32) % (uint64_t)(seq_len - read_len + 1));
+	int minus = (int)(synth_hash(read_seed, 3, r, 1) & 1);
+	uint64_t g = (uint64_t)(((unsigned __int128)i * n_genus) / n_seq);
+	uint64_t out = 0;
+	for (int k = 0; k < 32; k++) {
+		uint32_t pos = w * 32 + k; // position in the emitted read
+		if (pos >= read_len)
+			break;
+		uint32_t j = minus ? read_len - 1 - pos : pos; // position in the sampled window
+		uint32_t b = synth_db_base(seed, i, g, off + j);
+		uint64_t e = synth_hash(read_seed, 4, r, j >> 2);
+		uint32_t f = (uint32_t)(e >> (16 * (j & 3))) & 0xFFFF;
+		if (f < 655)
+			b = (b + 1 + f % 3) & 3;
+		if (minus)
+			b = 3 - b;
+		out |= (uint64_t)b << (2 * k);
+	}
+	fwd[t] = out;
+}
+
+static int reads_finish(pgx_reads *rd)
+{
+	// d_fwd (and d_fwd_amb) are filled; build offsets/lengths on device and the rc strand
+	PGX_TRY(rd->d_len.alloc((size_t)rd->n));
+	PGX_TRY(rd->d_woff.alloc((size_t)rd->n + 1));
+	PGX_TRY(rd->d_len.upload(rd->h_len.data(), (size_t)rd->n));
+	PGX_TRY(rd->d_woff.upload(rd->h_woff.data(), (size_t)rd->n + 1));
+	PGX_TRY(rd->d_rc.alloc((size_t)rd->n_words + 2, 0, 0, true));
+	if (rd->n == 0)
+		return 0;
+	int grid = (int)std::min<int64_t>(rd->n, 65535 * 16);
+	int block = rd->max_len > 2048 ? 256 : 64;
+	hipLaunchKernelGGL(k_revcomp, dim3(grid), dim3(block), 0, 0, rd->d_fwd.data(), rd->d_woff.data(),
+			   rd->d_len.data(), (uint64_t)rd->n, rd->d_rc.data(), 0);
+	PGX_HIP(hipGetLastError());
+	if (rd->has_amb) {
+		PGX_TRY(rd->d_rc_amb.alloc((size_t)rd->n_words + 2, 0, 0, true));
+		hipLaunchKernelGGL(k_revcomp, dim3(grid), dim3(block), 0, 0, rd->d_fwd_amb.data(), rd->d_woff.data(),
+				   rd->d_len.data(), (uint64_t)rd->n, rd->d_rc_amb.data(), 1);
+		PGX_HIP(hipGetLastError());
+	}
+	PGX_HIP(hipDeviceSynchronize());
+	return 0;
+}
+
+} // namespace pgx
+
+std::string pgx_reads::name_of(int64_t i) const
+{
+	if (synthetic)
+		return "r" + std::to_string(first + i);
+	return names[(size_t)i];
+}
+
+using namespace pgx;
+
+extern "C" {
+
+int pgx_db_build(const char *fasta_path, const char *prefix)
+{
+	if (!fasta_path || !prefix)
+		return fail(PGX_E_ARG, "pgx_db_build: null argument");
+	bool ok;
+	std::string text = read_text_file(fasta_path, &ok);
+	if (!ok)
+		return fail(PGX_E_IO, "cannot open FASTA file %s", fasta_path);
+	PackedSet ps;
+	pack_fasta_text(text, ps);
+	pgx_db *db = nullptr;
+	db_from_packed(ps, &db);
+	int rc = db_write_file(db, prefix);
+	delete db;
+	return rc;
+}
+
+int pgx_db_open(const char *prefix, pgx_db **out)
+{
+	if (!prefix || !out)
+		return fail(PGX_E_ARG, "pgx_db_open: null argument");
+	PGX_TRY(require_device());
+	pgx_db *db = nullptr;
+	PGX_TRY(db_read_file(prefix, &db));
+	int rc = db_upload_and_index(db);
+	if (rc < 0) {
+		delete db;
+		return rc;
+	}
+	*out = db;
+	return 0;
+}
+
+int pgx_db_from_fasta(const char *fasta_path, pgx_db **out)
+{
+	if (!fasta_path || !out)
+		return fail(PGX_E_ARG, "pgx_db_from_fasta: null argument");
+	PGX_TRY(require_device());
+	bool ok;
+	std::string text = read_text_file(fasta_path, &ok);
+	if (!ok)
+		return fail(PGX_E_IO, "cannot open FASTA file %s", fasta_path);
+	PackedSet ps;
+	pack_fasta_text(text, ps);
+	pgx_db *db = nullptr;
+	db_from_packed(ps, &db);
+	int rc = db_upload_and_index(db);
+	if (rc < 0) {
+		delete db;
+		return rc;
+	}
+	*out = db;
+	return 0;
+}
+
+void pgx_db_close(pgx_db *db) { delete db; }
+int64_t pgx_db_num_seqs(const pgx_db *db) { return db ? db->n_seq : 0; }
+int64_t pgx_db_num_bases(const pgx_db *db) { return db ? db->n_bases : 0; }
+const char *pgx_db_seq_id(const pgx_db *db, int64_t i)
+{
+	if (!db || i < 0 || i >= db->n_seq)
+		return nullptr;
+	return db->ids[(size_t)i].c_str();
+}
+
+void pgx_synth_default(pgx_synth_cfg *c)
+{
+	c->seed = 0x50414E47ull;
+	c->n_seq = 666667;
+	c->seq_len = 1500;
+	c->n_genus = 20000;
+	c->read_seed = 42;
+	c->read_len = 150;
+}
+
+int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out)
+{
+	if (!cfg || !out || cfg->n_seq <= 0 || cfg->seq_len <= 0 || cfg->n_genus <= 0)
+		return fail(PGX_E_ARG, "pgx_db_from_synth: bad configuration");
+	PGX_TRY(require_device());
+	pgx_db *db = new pgx_db();
+	db->n_seq = cfg->n_seq;
+	db->n_bases = cfg->n_seq * (int64_t)cfg->seq_len;
+	if (db->n_bases >= (1ll << 32) - 64) {
+		delete db;
+		return fail(PGX_E_LIMIT, "synthetic database exceeds the 32-bit position limit");
+	}
+	db->h_seq_off.resize((size_t)db->n_seq + 1);
+	for (int64_t i = 0; i <= db->n_seq; i++)
+		db->h_seq_off[(size_t)i] = (uint32_t)(i * cfg->seq_len);
+	db->ids.reserve((size_t)db->n_seq);
+	char buf[64];
+	for (int64_t i = 0; i < db->n_seq; i++) {
+		snprintf(buf, sizeof buf, "gi|%lld|syn|S%lld|", (long long)(1000 + i), (long long)i);
+		db->ids.emplace_back(buf);
+	}
+	size_t nw = ((size_t)db->n_bases + 31) / 32;
+	int rc = db->d_words.alloc(nw, 1, 2, true);
+	if (rc == 0) {
+		hipLaunchKernelGGL(k_synth_db, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, cfg->seed,
+				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint64_t)cfg->n_genus,
+				   db->d_words.data(), (uint64_t)nw, (uint64_t)db->n_bases);
+		if (hipGetLastError() != hipSuccess)
+			rc = fail(PGX_E_NODEVICE, "k_synth_db launch failed");
+	}
+	if (rc == 0)
+		rc = db_upload_offsets(db);
+	if (rc == 0)
+		rc = db_build_index(db);
+	if (rc < 0) {
+		delete db;
+		return rc;
+	}
+	*out = db;
+	return 0;
+}
+
+int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, pgx_reads **out)
+{
+	if (!cfg || !out || count < 0 || cfg->read_len <= 0 || cfg->read_len > cfg->seq_len)
+		return fail(PGX_E_ARG, "pgx_reads_from_synth: bad configuration");
+	PGX_TRY(require_device());
+	pgx_reads *rd = new pgx_reads();
+	rd->n = count;
+	rd->first = first;
+	rd->synthetic = true;
+	uint32_t wpr = ((uint32_t)cfg->read_len + 31) / 32;
+	rd->n_words = count * (int64_t)wpr;
+	rd->max_len = cfg->read_len;
+	rd->h_len.assign((size_t)count, (uint32_t)cfg->read_len);
+	rd->h_woff.resize((size_t)count + 1);
+	for (int64_t i = 0; i <= count; i++)
+		rd->h_woff[(size_t)i] = (uint32_t)(i * wpr);
+	int rc = rd->d_fwd.alloc((size_t)rd->n_words + 2, 0, 0, true);
+	if (rc == 0 && count > 0) {
+		uint64_t nt = (uint64_t)count * wpr;
+		hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, cfg->seed,
+				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint64_t)cfg->n_genus, cfg->read_seed,
+				   (uint32_t)cfg->read_len, (uint64_t)first, (uint64_t)count, wpr, rd->d_fwd.data());
+		if (hipGetLastError() != hipSuccess)
+			rc = fail(PGX_E_NODEVICE, "k_synth_reads launch failed");
+	}
+	if (rc == 0)
+		rc = reads_finish(rd);
+	if (rc < 0) {
+		delete rd;
+		return rc;
+	}
+	*out = rd;
+	return 0;
+}
+
+int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_reads **out)
+{
+	if (!path || !out)
+		return fail(PGX_E_ARG, "pgx_reads_from_fasta: null argument");
+	PGX_TRY(require_device());
+	bool ok;
+	std::string text = read_text_file(path, &ok);
+	if (!ok)
+		return fail(PGX_E_IO, "cannot open query file %s", path);
+	PackedSet ps;
+	pack_fasta_text(text, ps);
+	int64_t total = (int64_t)ps.headers.size();
+	if (first < 0)
+		first = 0;
+	if (first > total)
+		first = total;
+	if (count < 0 || first + count > total)
+		count = total - first;
+	pgx_reads *rd = new pgx_reads();
+	rd->n = count;
+	rd->first = first;
+	rd->has_amb = ps.any_amb;
+	rd->h_len.resize((size_t)count);
+	rd->h_woff.resize((size_t)count + 1);
+	uint64_t nw = 0;
+	for (int64_t i = 0; i < count; i++) {
+		uint64_t L = ps.off[(size_t)(first + i) + 1] - ps.off[(size_t)(first + i)];
+		rd->h_len[(size_t)i] = (uint32_t)L;
+		rd->h_woff[(size_t)i] = (uint32_t)nw;
+		nw += (L + 31) / 32;
+		if ((int32_t)L > rd->max_len)
+			rd->max_len = (int32_t)L;
+		rd->names.push_back(first_word(ps.headers[(size_t)(first + i)]));
+	}
+	rd->h_woff[(size_t)count] = (uint32_t)nw;
+	rd->n_words = (int64_t)nw;
+	// re-pack each read on its own word boundary
+	std::vector<uint64_t> fw(nw + 2, 0), fa(ps.any_amb ? nw + 2 : 0, 0);
+	auto get = [&](const std::vector<uint64_t> &src, uint64_t p) -> uint64_t {
+		return (src[p >> 5] >> (2 * (p & 31))) & 3;
+	};
+	for (int64_t i = 0; i < count; i++) {
+		uint64_t s = ps.off[(size_t)(first + i)], L = rd->h_len[(size_t)i], w0 = rd->h_woff[(size_t)i];
+		for (uint64_t k = 0; k < L; k++) {
+			fw[w0 + (k >> 5)] |= get(ps.words, s + k) << (2 * (k & 31));
+			if (ps.any_amb)
+				fa[w0 + (k >> 5)] |= (get(ps.amb, s + k) & 1) << (2 * (k & 31));
+		}
+	}
+	int rc = rd->d_fwd.alloc((size_t)nw + 2, 0, 0, true);
+	if (rc == 0)
+		rc = rd->d_fwd.upload(fw.data(), (size_t)nw);
+	if (rc == 0 && ps.any_amb) {
+		rc = rd->d_fwd_amb.alloc((size_t)nw + 2, 0, 0, true);
+		if (rc == 0)
+			rc = rd->d_fwd_amb.upload(fa.data(), (size_t)nw);
+	}
+	if (rc == 0)
+		rc = reads_finish(rd);
+	if (rc < 0) {
+		delete rd;
+		return rc;
+	}
+	*out = rd;
+	return 0;
+}
+
+void pgx_reads_close(pgx_reads *r) { delete r; }
+int64_t pgx_reads_count(const pgx_reads *r) { return r ? r->n : 0; }
+
+int pgx_reads_get(const pgx_reads *r, int64_t i, uint8_t *bases_out, int32_t cap, int32_t *len_out)
+{
+	if (!r || i < 0 || i >= r->n || !bases_out)
+		return fail(PGX_E_ARG, "pgx_reads_get: bad argument");
+	uint32_t L = r->h_len[(size_t)i], w0 = r->h_woff[(size_t)i], nw = (L + 31) / 32;
+	std::vector<uint64_t> w(nw), a(nw, 0);
+	PGX_TRY(r->d_fwd.download(w.data(), nw, w0));
+	if (r->has_amb)
+		PGX_TRY(r->d_fwd_amb.download(a.data(), nw, w0));
+	for (uint32_t k = 0; k < L && (int32_t)k < cap; k++) {
+		uint8_t b = (uint8_t)((w[k >> 5] >> (2 * (k & 31))) & 3);
+		if ((a[k >> 5] >> (2 * (k & 31))) & 1)
+			b = 4;
+		bases_out[k] = b;
+	}
+	if (len_out)
+		*len_out = (int32_t)L;
+	return 0;
+}
+
+int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out)
+{
+	if (!db || !out)
+		return fail(PGX_E_ARG, "pgx_db_get_shape: null argument");
+	out->n_seq = db->n_seq;
+	out->n_bases = db->n_bases;
+	out->has_amb = db->has_amb;
+	out->index_bits = db->index_bits;
+	out->n_postings = db->n_postings;
+	return 0;
+}
+
+int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
+{
+	if (!db || !out)
+		return fail(PGX_E_ARG, "pgx_db_device_arrays: null argument");
+	int n = 0;
+	auto add = [&](const char *name, void *p, size_t bytes) {
+		if (n < cap) {
+			out[n].name = name;
+			out[n].ptr = p;
+			out[n].bytes = bytes;
+		}
+		n++;
+	};
+	add("words", db->d_words.data(), db->d_words.bytes());
+	if (db->has_amb)
+		add("amb", db->d_amb.data(), db->d_amb.bytes());
+	add("seq_off", db->d_seq_off.data(), db->d_seq_off.bytes());
+	add("blk_subj", db->d_blk_subj.data(), db->d_blk_subj.bytes());
+	add("bucket_off", db->d_bucket_off.data(), db->d_bucket_off.bytes());
+	add("postings", db->d_postings.data(), db->d_postings.bytes());
+	return n;
+}
+
+int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
+{
+	if (!s || !out)
+		return fail(PGX_E_ARG, "pgx_db_alloc_like: null argument");
+	PGX_TRY(require_device());
+	pgx_db *db = new pgx_db();
+	db->n_seq = s->n_seq;
+	db->n_bases = s->n_bases;
+	db->has_amb = s->has_amb != 0;
+	db->index_bits = s->index_bits;
+	db->n_postings = s->n_postings;
+	size_t nw = ((size_t)db->n_bases + 31) / 32;
+	int rc = db->d_words.alloc(nw, 1, 2, true);
+	if (rc == 0 && db->has_amb)
+		rc = db->d_amb.alloc(nw, 1, 2, true);
+	if (rc == 0)
+		rc = db->d_seq_off.alloc((size_t)db->n_seq + 1);
+	if (rc == 0)
+		rc = db->d_blk_subj.alloc(((size_t)db->n_bases + 63) / 64 + 1);
+	if (rc == 0)
+		rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
+	if (rc == 0)
+		rc = db->d_postings.alloc(db->n_postings ? (size_t)db->n_postings : 1);
+	if (rc < 0) {
+		delete db;
+		return rc;
+	}
+	*out = db;
+	return 0;
+}
+
+int pgx_db_finish_import(pgx_db *db)
+{
+	if (!db)
+		return fail(PGX_E_ARG, "pgx_db_finish_import: null argument");
+	db->h_seq_off.resize((size_t)db->n_seq + 1);
+	PGX_TRY(db->d_seq_off.download(db->h_seq_off.data(), (size_t)db->n_seq + 1));
+	return 0;
+}
+}
