@@ -1,0 +1,30 @@
+// blastn — `blastn -query F -db DB -outfmt 6 -out O` (reference README.md:96,
+// Scripts/run_multi_blastn.pl:56). -rank/-world_size shard the queries the way mpiblastn's ranks do
+// (Scripts/submit_MPI-blast.job:24); concatenating the rank outputs in order gives the 1-process file.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "pangea_hip.h"
+
+int main(int argc, char **argv)
+{
+	pgx_blastn_opts o = { nullptr, nullptr, nullptr, 6, 0, 1 };
+	for (int i = 1; i + 1 < argc; i++) {
+		if (!strcmp(argv[i], "-query")) o.query_path = argv[++i];
+		else if (!strcmp(argv[i], "-db")) o.db_prefix = argv[++i];
+		else if (!strcmp(argv[i], "-out")) o.out_path = argv[++i];
+		else if (!strcmp(argv[i], "-outfmt")) o.outfmt = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-rank")) o.rank = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-world_size")) o.world_size = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-num_threads")) ++i; // accepted, the GPU does the work
+	}
+	if (!o.query_path || !o.db_prefix || !o.out_path) {
+		fprintf(stderr, "USAGE\n  blastn -query <File_In> -db <database_name> -outfmt 6 -out <File_Out>\n");
+		return 1;
+	}
+	if (pgx_blastn_run(&o) < 0) {
+		fprintf(stderr, "BLAST engine error: %s\n", pgx_last_error());
+		return 2;
+	}
+	return 0;
+}

@@ -1,0 +1,38 @@
+// soap — `soap -a reads -D ref.fa.index -o out [-u unmapped] [-M 4] [-r 0|1|2] [-n 5] [-p N]`
+// (reference README.md:134, soap.man:29-83). -p is accepted and ignored: the GPU does the work.
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+#include "pangea_hip.h"
+
+int main(int argc, char **argv)
+{
+	pgx_soap_opts o = { nullptr, nullptr, nullptr, nullptr, 4, 1, 5, 0 };
+	int c;
+	while ((c = getopt(argc, argv, "a:D:o:u:M:r:n:p:tb:2:m:x:l:s:v:g:R")) != -1) {
+		switch (c) {
+		case 'a': o.reads_path = optarg; break;
+		case 'D': o.db_prefix = optarg; break;
+		case 'o': o.out_path = optarg; break;
+		case 'u': o.unmapped_path = optarg; break;
+		case 'M': o.match_mode = atoi(optarg); break;
+		case 'r': o.repeat_mode = atoi(optarg); break;
+		case 'n': o.max_n = atoi(optarg); break;
+		case 't': o.report_id = 1; break;
+		case 'p': break;
+		case 'b': case '2': case 'm': case 'x': case 'R':
+			fprintf(stderr, "soap: paired-end options are not implemented\n");
+			return 1;
+		default: break;
+		}
+	}
+	if (!o.reads_path || !o.db_prefix || !o.out_path) {
+		fprintf(stderr, "Usage: soap -a <query.file.a> -D <in.fasta.index> -o <alignment.output> [options]\n");
+		return 1;
+	}
+	if (pgx_soap_run(&o) < 0) {
+		fprintf(stderr, "soap: %s\n", pgx_last_error());
+		return 2;
+	}
+	return 0;
+}

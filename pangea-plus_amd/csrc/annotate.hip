@@ -1,0 +1,916 @@
+// Tax annotate and consensus verbs, and the glue that binds a sequence database to a taxonomy.
+//
+//   pgx_taxcollect_file     `perl NCBI-taxcollector-0.01.pl -f in -o out` (NCBI-taxcollector-0.01.pl:20-164):
+//                           host parses the hit table, ONE kernel walks every gi (taxdb.hip), host renders
+//                           the lineage text with the driver's digit / underscore rules (taxcollector:96-144)
+//   pgx_db_bind_taxonomy    the same walk once per database subject; lineage text and consensus tokens
+//                           stay in HBM for the fused pipeline
+//   pgx_consensus_file      `perl Consensus_BLAST_SOAP_RDP-1.1.pl -b -r [-s] -o` (Consensus:8-244): the cursor
+//                           logic over the two files is control flow on ids (host); agreement counting and
+//                           the order-dependent arg-max run on the device (consensus_core.hpp)
+#include <algorithm>
+#include <map>
+
+#include "bitops.hpp"
+#include "consensus_core.hpp"
+#include "engine.hpp"
+#include "taxdb.hpp"
+
+namespace pgx {
+
+void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, Text &out);
+
+// ------------------------------------------------------------------------------------------ lineage text
+LineageRenderer::~LineageRenderer() { delete cache; }
+
+// "[idx]" followed by "name;|" when `tax_class -n` yields a scientific name (taxcollector:264-273)
+std::string LineageRenderer::piece(int32_t taxid)
+{
+	if (!cache)
+		cache = new std::unordered_map<int32_t, std::string>();
+	auto it = cache->find(taxid);
+	if (it != cache->end())
+		return it->second;
+	pgx_node nd;
+	tax_node_record(db, taxid, &nd);
+	char idx[16];
+	snprintf(idx, sizeof idx, "[%d]", (int)driver_rank_code(nd.rank));
+	std::string s = idx, name;
+	if (tax_scientific_name(db, taxid, name))
+		s += name + ";|";
+	(*cache)[taxid] = s;
+	return s;
+}
+
+static inline bool perl_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
+
+std::string LineageRenderer::render(const int32_t *lineage, int count, int status, const std::string &gi_text)
+{
+	std::string cat;
+	if (status == 1) {
+		cat = "Unidentified(GI:" + gi_text + ");|";
+	} else {
+		for (int k = 0; k < count; k++)
+			cat += lineage[k] == PGX_LIN_UNCLASSIFIED ? std::string("[0]Unclassified;|") : piece(lineage[k]);
+	}
+	// split on '|', trailing empty elements dropped (taxcollector:96-97)
+	std::vector<std::string> el;
+	size_t s = 0;
+	while (s <= cat.size()) {
+		size_t bar = cat.find('|', s);
+		if (bar == std::string::npos)
+			bar = cat.size();
+		el.emplace_back(cat, s, bar - s);
+		if (bar == cat.size())
+			break;
+		s = bar + 1;
+	}
+	while (!el.empty() && el.back().empty())
+		el.pop_back();
+	bool any5 = false;
+	for (auto &e : el)
+		if (e.find('5') != std::string::npos)
+			any5 = true;
+	std::string out;
+	for (size_t i = el.size(); i-- > 0;) {
+		std::string e = el[i];
+		size_t six = e.find('6');
+		if (six != std::string::npos) {
+			// species branch (taxcollector:109-126): blanks -> '_'; without any '5' print the element
+			// twice, first with its first '6' turned into '5'
+			for (auto &c : e)
+				if (perl_space(c))
+					c = '_';
+			if (!any5) {
+				e[six] = '5';
+				out += e;
+				e[six] = '6';
+			}
+			out += e;
+		} else {
+			size_t sev = e.find('7');
+			if (sev != std::string::npos)
+				e[sev] = '9'; // taxcollector:130-134
+			out += e;
+		}
+	}
+	return out;
+}
+
+// split(/\ |\t\t|\t/, line): leading empty fields kept, trailing dropped (taxcollector:77)
+static void split_columns(const std::string &line, std::vector<std::string> &f)
+{
+	f.clear();
+	size_t s = 0, i = 0;
+	while (i < line.size()) {
+		int sep = 0;
+		if (line[i] == ' ')
+			sep = 1;
+		else if (line[i] == '\t')
+			sep = (i + 1 < line.size() && line[i + 1] == '\t') ? 2 : 1;
+		if (sep) {
+			f.emplace_back(line, s, i - s);
+			i += sep;
+			s = i;
+		} else {
+			i++;
+		}
+	}
+	f.emplace_back(line, s, line.size() - s);
+	while (!f.empty() && f.back().empty())
+		f.pop_back();
+}
+
+// one output line of the driver: id, lineage, then input columns 2..12 that are not empty
+static void emit_collected(const std::string &line, const std::string &lineage, std::string &out)
+{
+	std::vector<std::string> f;
+	split_columns(line, f);
+	if (!f.empty())
+		out += f[0];
+	out += '\t';
+	out += lineage;
+	for (size_t i = 2; i <= 12 && i < f.size(); i++)
+		if (!f[i].empty()) {
+			out += '\t';
+			out += f[i];
+		}
+	out += '\n';
+}
+
+// text between the first and second '|' (taxcollector:75,84); false when the line has no '|'
+static bool gi_text_of(const std::string &line, std::string &gi)
+{
+	size_t a = line.find('|');
+	if (a == std::string::npos)
+		return false;
+	size_t b = line.find('|', a + 1);
+	gi = line.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1);
+	return true;
+}
+
+uint32_t intern_into(std::unordered_map<std::string, uint32_t> &map, std::vector<std::string> &text, const std::string &s)
+{
+	auto it = map.find(s);
+	if (it != map.end())
+		return it->second;
+	uint32_t id = (uint32_t)text.size();
+	text.push_back(s);
+	map.emplace(s, id);
+	return id;
+}
+
+// Consensus:116-122: split on '[', ']', ';', join with blanks, split on whitespace
+static void lineage_tokens(const std::string &tax, std::vector<std::string> &tok)
+{
+	tok.clear();
+	size_t i = 0;
+	auto delim = [](char c) { return perl_space(c) || c == '[' || c == ']' || c == ';'; };
+	while (i < tax.size()) {
+		while (i < tax.size() && delim(tax[i]))
+			i++;
+		size_t s = i;
+		while (i < tax.size() && !delim(tax[i]))
+			i++;
+		if (i > s)
+			tok.emplace_back(tax, s, i - s);
+	}
+}
+
+static int8_t blast_rank_index(const std::string &t)
+{
+	return (t.size() == 1 && t[0] >= '0' && t[0] <= '6') ? (int8_t)(t[0] - '0') : (int8_t)-1;
+}
+
+static int8_t rdp_rank_index(const std::string &t)
+{
+	static const char *const r[7] = { "domain", "phylum", "class", "order", "family", "genus", "species" };
+	for (int i = 0; i < 7; i++)
+		if (t == r[i])
+			return (int8_t)i;
+	return -1;
+}
+
+// Consensus:159-160: quotes and backslashes, then every [\W\d_] removed: ASCII letters remain
+static std::string clean_rdp_name(const std::string &s)
+{
+	std::string o;
+	for (char c : s)
+		if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))
+			o += c;
+	return o;
+}
+
+// similarity strings -> ranks of their byte order ("" and "0" always present: the start values of
+// $blastsim, Consensus:86-92 and :231)
+static void build_sim_ranks(std::vector<std::string> uniq, std::map<std::string, uint32_t> &rank)
+{
+	uniq.push_back("");
+	uniq.push_back("0");
+	std::sort(uniq.begin(), uniq.end());
+	uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+	for (size_t i = 0; i < uniq.size(); i++)
+		rank[uniq[i]] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+// one lane per group of consecutive hit lines (file verb) — hits are already in table order
+__global__ void k_consensus_groups(const uint32_t *__restrict__ g_first, const uint32_t *__restrict__ g_count,
+				   const uint32_t *__restrict__ g_rdp, const uint32_t *__restrict__ g_initsim, uint32_t n_groups,
+				   const uint32_t *__restrict__ tok_off, const uint32_t *__restrict__ tok,
+				   const int8_t *__restrict__ tok_rank, const uint32_t *__restrict__ simrank,
+				   const uint32_t *__restrict__ rdp_off, const uint32_t *__restrict__ rdp_name,
+				   const int8_t *__restrict__ rdp_rank, pgx_consensus_rec *__restrict__ recs)
+{
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups)
+		return;
+	const uint32_t first = g_first[g], n = g_count[g], rl = g_rdp[g];
+	const uint32_t r0 = rdp_off[rl], r1 = rdp_off[rl + 1];
+	ArgmaxState am;
+	am.cursim = g_initsim[g];
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t line = first + k, t0 = tok_off[line], nt = tok_off[line + 1] - t0;
+		const uint32_t rm = rank_matches(tok + t0, nt, tok_rank, rdp_name, rdp_rank, r0, r1);
+		am.step((int32_t)line, rm, nt, simrank[line]);
+	}
+	recs[g].hit = am.win;
+	recs[g].matches = (int32_t)am.maxrm;
+}
+
+// synthetic RDP stream: 6 fixed slots per read (domain..genus); a dropped rank gets a name id and a
+// rank index that equal nothing
+__global__ void k_synth_rdp(uint64_t read_seed, uint64_t n_seq, uint32_t seq_len, uint32_t read_len, uint64_t first,
+			    uint64_t count, const int64_t *__restrict__ level_cnt, const int64_t *__restrict__ level_base,
+			    const uint32_t *__restrict__ node_name_tok, uint32_t *__restrict__ name, int8_t *__restrict__ rank)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count)
+		return;
+	const uint64_t r = first + i;
+	const uint64_t u = synth_hash(read_seed, 3, r, 0);
+	(void)seq_len;
+	(void)read_len;
+	int64_t idx = (int64_t)((u & 0xFFFFFFFFull) % n_seq); // species index = source sequence
+	int64_t anc[6];
+	for (int l = 5; l >= 0; l--) {
+		idx = (int64_t)(((unsigned __int128)idx * (uint64_t)level_cnt[l]) / (uint64_t)level_cnt[l + 1]);
+		anc[l] = idx;
+	}
+	for (int k = 0; k < 6; k++) {
+		const bool keep = synth_hash(read_seed, 5, r, (uint64_t)k) % 10 != 0;
+		const int64_t taxid = level_base[k] + anc[k];
+		name[i * 6 + k] = keep ? node_name_tok[taxid] : 0xFFFFFFFFu;
+		rank[i * 6 + k] = keep ? (int8_t)k : (int8_t)-2;
+	}
+}
+
+} // namespace pgx
+
+using namespace pgx;
+
+uint32_t pgx_db::intern(const std::string &s) { return intern_into(token_id, token_text, s); }
+
+extern "C" {
+
+int pgx_taxcollect_file(pgx_taxdb *db, const char *in_path, const char *out_path, char **report_text)
+{
+	Text report;
+	auto done = [&](int rc) {
+		if (report_text)
+			*report_text = report.release_malloc(nullptr);
+		return rc;
+	};
+	if (!db || !in_path || !out_path)
+		return done(fail(PGX_E_ARG, "taxcollector: -f and -o are required"));
+	int rc = require_device();
+	if (rc < 0)
+		return done(rc);
+	bool ok;
+	std::string text = read_text_file(in_path, &ok);
+	if (!ok) {
+		report.printf("Error: Unable to open classification results file %s.\n", in_path); // taxcollector:31-34
+		return done(fail(PGX_E_IO, "cannot open %s", in_path));
+	}
+	// pass 1 (host): lines up to the first empty one (taxcollector:83-87), their gi texts
+	std::vector<std::string> lines, gis;
+	std::vector<int32_t> gi_num;
+	int hang_line = -1;
+	for (size_t s = 0; s < text.size();) {
+		size_t e = text.find('\n', s);
+		if (e == std::string::npos)
+			e = text.size();
+		std::string line(text, s, e - s);
+		s = e + 1;
+		if (line.find_first_not_of('|') == std::string::npos)
+			break;
+		std::string g;
+		if (!gi_text_of(line, g) || g.empty()) {
+			hang_line = (int)lines.size();
+			break; // `./tax_class -s` without an id: the reference recurses forever
+		}
+		lines.push_back(line);
+		gis.push_back(g);
+		gi_num.push_back(atoi(g.c_str()));
+	}
+	// pass 2 (device): one walk per line
+	const size_t n = lines.size();
+	std::vector<int32_t> lin(n * PGX_LINEAGE_SLOTS), cnt(n), st(n), leaf(n);
+	if (n) {
+		DevBuf<int32_t> d_gi, d_lin, d_cnt, d_st, d_leaf;
+		rc = d_gi.alloc(n);
+		if (rc == 0) rc = d_lin.alloc(n * PGX_LINEAGE_SLOTS, 0, 0, true);
+		if (rc == 0) rc = d_cnt.alloc(n);
+		if (rc == 0) rc = d_st.alloc(n);
+		if (rc == 0) rc = d_leaf.alloc(n);
+		if (rc == 0) rc = d_gi.upload(gi_num.data(), n);
+		if (rc == 0) rc = tax_walk_device(db, d_gi.data(), (int64_t)n, d_lin.data(), d_cnt.data(), d_st.data(), d_leaf.data());
+		if (rc == 0) rc = d_lin.download(lin.data(), lin.size());
+		if (rc == 0) rc = d_cnt.download(cnt.data(), n);
+		if (rc == 0) rc = d_st.download(st.data(), n);
+		if (rc == 0) rc = d_leaf.download(leaf.data(), n);
+		if (rc < 0)
+			return done(rc);
+	}
+	// pass 3 (host): text
+	LineageRenderer ren(db);
+	std::string out;
+	int status = 0;
+	for (size_t i = 0; i < n; i++) {
+		if (st[i] == 2 || st[i] == 3) {
+			status = st[i] == 2 ? fail(PGX_E_REFHANG, "line %zu (GI %s): the reference driver never terminates on this taxonomy walk", i + 1, gis[i].c_str())
+					    : fail(PGX_E_LIMIT, "line %zu: lineage longer than %d elements", i + 1, PGX_LINEAGE_SLOTS);
+			break;
+		}
+		if (st[i] == 1) {
+			report.s += "Searching upper node for TAXID 0\n.\n"; // taxcollector:176 with "0\n"
+			report.printf("\n\nTAXID zero GI = %s.\n\n", gis[i].c_str());
+		} else {
+			report.printf("Searching upper node for TAXID %d.\n", leaf[i]);
+			report.printf("Done for TAXID %d.\n", leaf[i]);
+		}
+		emit_collected(lines[i], ren.render(&lin[i * PGX_LINEAGE_SLOTS], cnt[i], st[i], gis[i]), out);
+	}
+	if (status == 0 && hang_line >= 0)
+		status = fail(PGX_E_REFHANG, "line %d has no gi|N| subject id: the reference driver never terminates on it", hang_line + 1);
+	int wrc = write_text_file(out_path, out);
+	if (wrc < 0) {
+		report.printf("Error: Unable to open output file %s.\n", out_path);
+		return done(wrc);
+	}
+	return done(status);
+}
+
+int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
+{
+	if (!db || !tax)
+		return fail(PGX_E_ARG, "pgx_db_bind_taxonomy: null argument");
+	PGX_TRY(require_device());
+	const size_t n = (size_t)db->n_seq;
+	std::vector<int32_t> gi(n);
+	std::vector<std::string> gi_text(n);
+	for (size_t i = 0; i < n; i++) {
+		if (!gi_text_of(db->ids[i], gi_text[i]) || gi_text[i].empty())
+			return fail(PGX_E_REFHANG, "subject %s has no gi|N| id: the reference driver cannot annotate it", db->ids[i].c_str());
+		gi[i] = atoi(gi_text[i].c_str());
+	}
+	std::vector<int32_t> lin(n * PGX_LINEAGE_SLOTS), cnt(n), st(n), leaf(n);
+	{
+		DevBuf<int32_t> d_gi, d_lin, d_cnt, d_st, d_leaf;
+		PGX_TRY(d_gi.alloc(n));
+		PGX_TRY(d_lin.alloc(n * PGX_LINEAGE_SLOTS, 0, 0, true));
+		PGX_TRY(d_cnt.alloc(n));
+		PGX_TRY(d_st.alloc(n));
+		PGX_TRY(d_leaf.alloc(n));
+		PGX_TRY(d_gi.upload(gi.data(), n));
+		PGX_TRY(tax_walk_device(tax, d_gi.data(), (int64_t)n, d_lin.data(), d_cnt.data(), d_st.data(), d_leaf.data()));
+		PGX_TRY(d_lin.download(lin.data(), lin.size()));
+		PGX_TRY(d_cnt.download(cnt.data(), n));
+		PGX_TRY(d_st.download(st.data(), n));
+		PGX_TRY(d_leaf.download(leaf.data(), n));
+	}
+	LineageRenderer ren(tax);
+	db->lineage.assign(n, std::string());
+	db->subj_taxid.assign(n, 0);
+	db->token_text.clear();
+	db->token_id.clear();
+	db->intern(""); // id 0 = the empty string (what an undefined name compares as)
+	std::vector<uint32_t> off(n + 1, 0), toks;
+	toks.reserve(n * 14);
+	std::vector<std::string> tk;
+	for (size_t i = 0; i < n; i++) {
+		if (st[i] >= 2)
+			return fail(PGX_E_REFHANG, "subject %s: the reference driver never terminates on its taxonomy walk", db->ids[i].c_str());
+		db->lineage[i] = ren.render(&lin[i * PGX_LINEAGE_SLOTS], cnt[i], st[i], gi_text[i]);
+		db->subj_taxid[i] = leaf[i];
+		lineage_tokens(db->lineage[i], tk);
+		for (auto &t : tk)
+			toks.push_back(db->intern(t));
+		off[i + 1] = (uint32_t)toks.size();
+	}
+	db->h_tok_rank.resize(db->token_text.size());
+	for (size_t t = 0; t < db->token_text.size(); t++)
+		db->h_tok_rank[t] = blast_rank_index(db->token_text[t]);
+	PGX_TRY(db->d_subj_tok_off.alloc(n + 1));
+	PGX_TRY(db->d_subj_tok_off.upload(off.data(), n + 1));
+	PGX_TRY(db->d_subj_tok.alloc(toks.size() ? toks.size() : 1));
+	PGX_TRY(db->d_subj_tok.upload(toks.data(), toks.size()));
+	PGX_TRY(db->d_tok_rank.alloc(db->h_tok_rank.size()));
+	PGX_TRY(db->d_tok_rank.upload(db->h_tok_rank.data(), db->h_tok_rank.size()));
+	// similarity order of every "%.2f" text from 0.00 to 100.00, plus "" and "0"
+	std::vector<std::string> sims;
+	char buf[16];
+	for (int h = 0; h <= 10000; h++) {
+		snprintf(buf, sizeof buf, "%d.%02d", h / 100, h % 100);
+		sims.emplace_back(buf);
+	}
+	std::map<std::string, uint32_t> rank;
+	build_sim_ranks(sims, rank);
+	std::vector<uint32_t> lut(10001);
+	for (int h = 0; h <= 10000; h++)
+		lut[(size_t)h] = rank[sims[(size_t)h]];
+	db->simrank_undef = rank[""];
+	db->simrank_zero = rank["0"];
+	PGX_TRY(db->d_simrank_lut.alloc(lut.size()));
+	PGX_TRY(db->d_simrank_lut.upload(lut.data(), lut.size()));
+	// taxid -> token id of its cleaned scientific name (what an RDP assignment of that node would carry)
+	std::vector<uint32_t> nn(tax->n_nodes + 1, 0);
+	{
+		// only the nodes that occur in a bound lineage matter
+		std::vector<uint8_t> seen(tax->n_nodes + 1, 0);
+		for (size_t i = 0; i < n; i++)
+			for (int k = 0; k < cnt[i]; k++) {
+				int32_t t = lin[i * PGX_LINEAGE_SLOTS + k];
+				if (t > 0 && (size_t)t <= tax->n_nodes && !seen[(size_t)t]) {
+					seen[(size_t)t] = 1;
+					std::string name;
+					if (tax_scientific_name(tax, t, name))
+						nn[(size_t)t] = db->intern(clean_rdp_name(name));
+				}
+			}
+	}
+	PGX_TRY(db->d_node_name_tok.alloc(nn.size()));
+	PGX_TRY(db->d_node_name_tok.upload(nn.data(), nn.size()));
+	db->bound = true;
+	return 0;
+}
+
+const char *pgx_db_subject_lineage(const pgx_db *db, int64_t subject)
+{
+	if (!db || !db->bound || subject < 0 || subject >= db->n_seq)
+		return nullptr;
+	return db->lineage[(size_t)subject].c_str();
+}
+
+void pgx_rdp_close(pgx_rdp *r) { delete r; }
+
+int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cdb, pgx_rdp **out)
+{
+	pgx_db *db = const_cast<pgx_db *>(cdb);
+	if (!path || !reads || !db || !out)
+		return fail(PGX_E_ARG, "pgx_rdp_from_file: null argument");
+	if (!db->bound)
+		return fail(PGX_E_ARG, "pgx_rdp_from_file: bind the database to a taxonomy first");
+	PGX_TRY(require_device());
+	bool ok;
+	std::string text = read_text_file(path, &ok);
+	if (!ok)
+		return fail(PGX_E_IO, "cannot open RDP file %s", path);
+	const size_t n = (size_t)reads->n;
+	std::vector<uint32_t> off(n + 1, 0), name;
+	std::vector<int8_t> rank;
+	std::vector<uint8_t> present(n ? n : 1, 0);
+	std::vector<std::vector<std::pair<uint32_t, int8_t>>> per(n);
+	size_t cursor = 0;
+	for (size_t s = 0; s < text.size();) {
+		size_t e = text.find('\n', s);
+		if (e == std::string::npos)
+			e = text.size();
+		std::string line(text, s, e - s);
+		s = e + 1;
+		size_t five = line.find("\t\t\t\t\t");
+		std::string id = five == std::string::npos ? line : line.substr(0, five);
+		size_t r = cursor;
+		while (r < n && reads->name_of((int64_t)r) != id)
+			r++;
+		if (r >= n)
+			continue; // an RDP line for a read that is not in this batch
+		cursor = r + 1;
+		present[r] = 1;
+		if (five == std::string::npos)
+			continue;
+		std::string rest = line.substr(five + 5);
+		size_t again = rest.find("\t\t\t\t\t");
+		if (again != std::string::npos)
+			rest.resize(again);
+		std::vector<std::string> f;
+		for (size_t a = 0; a <= rest.size();) {
+			size_t t = rest.find('\t', a);
+			if (t == std::string::npos)
+				t = rest.size();
+			f.emplace_back(rest, a, t - a);
+			a = t + 1;
+		}
+		while (!f.empty() && f.back().empty())
+			f.pop_back();
+		for (size_t b = 0; b < f.size(); b += 3)
+			per[r].emplace_back(db->intern(clean_rdp_name(f[b])), b + 1 < f.size() ? rdp_rank_index(f[b + 1]) : (int8_t)-1);
+	}
+	for (size_t r = 0; r < n; r++) {
+		for (auto &p : per[r]) {
+			name.push_back(p.first);
+			rank.push_back(p.second);
+		}
+		off[r + 1] = (uint32_t)name.size();
+	}
+	pgx_rdp *rd = new pgx_rdp();
+	rd->n = (int64_t)n;
+	int rc = rd->d_off.alloc(n + 1);
+	if (rc == 0) rc = rd->d_off.upload(off.data(), n + 1);
+	if (rc == 0) rc = rd->d_name.alloc(name.size() ? name.size() : 1);
+	if (rc == 0) rc = rd->d_name.upload(name.data(), name.size());
+	if (rc == 0) rc = rd->d_rank.alloc(rank.size() ? rank.size() : 1);
+	if (rc == 0) rc = rd->d_rank.upload(rank.data(), rank.size());
+	if (rc == 0) rc = rd->d_present.alloc(present.size());
+	if (rc == 0) rc = rd->d_present.upload(present.data(), present.size());
+	if (rc < 0) {
+		delete rd;
+		return rc;
+	}
+	*out = rd;
+	return 0;
+}
+
+static void synth_level_counts(const pgx_synth_cfg *c, int64_t cnt[7], int64_t base[7])
+{
+	auto max1 = [](int64_t v) { return v < 1 ? (int64_t)1 : v; };
+	cnt[6] = c->n_seq;
+	cnt[5] = c->n_genus;
+	cnt[4] = max1(cnt[5] / 5);
+	cnt[3] = max1(cnt[4] / 4);
+	cnt[2] = max1(cnt[3] / 5);
+	cnt[1] = max1(cnt[2] / 5);
+	cnt[0] = max1(cnt[1] / 20);
+	int64_t b = 2;
+	for (int l = 0; l < 7; l++) {
+		base[l] = b;
+		b += cnt[l];
+	}
+}
+
+int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, const pgx_db *db, pgx_rdp **out)
+{
+	if (!cfg || !db || !out || count < 0)
+		return fail(PGX_E_ARG, "pgx_rdp_from_synth: bad argument");
+	if (!db->bound)
+		return fail(PGX_E_ARG, "pgx_rdp_from_synth: bind the database to the synthetic taxonomy first");
+	PGX_TRY(require_device());
+	int64_t cnt[7], base[7];
+	synth_level_counts(cfg, cnt, base);
+	if ((size_t)(base[6] + cnt[6]) > db->d_node_name_tok.n)
+		return fail(PGX_E_ARG, "bound taxonomy is smaller than the synthetic one");
+	DevBuf<int64_t> d_cnt, d_base;
+	PGX_TRY(d_cnt.alloc(7));
+	PGX_TRY(d_base.alloc(7));
+	PGX_TRY(d_cnt.upload(cnt, 7));
+	PGX_TRY(d_base.upload(base, 7));
+	pgx_rdp *rd = new pgx_rdp();
+	rd->n = count;
+	std::vector<uint32_t> off((size_t)count + 1);
+	for (int64_t i = 0; i <= count; i++)
+		off[(size_t)i] = (uint32_t)(6 * i);
+	int rc = rd->d_off.alloc((size_t)count + 1);
+	if (rc == 0) rc = rd->d_off.upload(off.data(), off.size());
+	if (rc == 0) rc = rd->d_name.alloc((size_t)count * 6 + 1);
+	if (rc == 0) rc = rd->d_rank.alloc((size_t)count * 6 + 1);
+	if (rc == 0) rc = rd->d_present.alloc((size_t)count + 1);
+	if (rc == 0 && hipMemset(rd->d_present.data(), 1, (size_t)count + 1) != hipSuccess)
+		rc = fail(PGX_E_NODEVICE, "hipMemset failed");
+	if (rc == 0 && count > 0) {
+		hipLaunchKernelGGL(k_synth_rdp, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, cfg->read_seed,
+				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint32_t)cfg->read_len, (uint64_t)first,
+				   (uint64_t)count, d_cnt.data(), d_base.data(), db->d_node_name_tok.data(), rd->d_name.data(),
+				   rd->d_rank.data());
+		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+			rc = fail(PGX_E_NODEVICE, "k_synth_rdp failed");
+	}
+	if (rc < 0) {
+		delete rd;
+		return rc;
+	}
+	*out = rd;
+	return 0;
+}
+
+int pgx_synth_write_taxdump(const pgx_synth_cfg *c, const char *dir)
+{
+	if (!c || !dir)
+		return fail(PGX_E_ARG, "pgx_synth_write_taxdump: null argument");
+	static const char *const rank_name[7] = { "superkingdom", "phylum", "class", "order", "family", "genus", "species" };
+	static const char *const prefix[6] = { "Dom", "Phy", "Cls", "Ord", "Fam", "Gen" };
+	int64_t cnt[7], base[7];
+	synth_level_counts(c, cnt, base);
+	std::string d = dir;
+	FILE *fn = fopen((d + "/nodes.dmp").c_str(), "w");
+	FILE *fm = fopen((d + "/names.dmp").c_str(), "w");
+	FILE *fg = fopen((d + "/gi_taxid_nucl.dmp").c_str(), "w");
+	if (!fn || !fm || !fg) {
+		if (fn) fclose(fn);
+		if (fm) fclose(fm);
+		if (fg) fclose(fg);
+		return fail(PGX_E_IO, "cannot write taxonomy dumps into %s", dir);
+	}
+	auto alpha5 = [](int64_t k, char *o) {
+		for (int p = 4; p >= 0; p--) {
+			o[p] = (char)('a' + k % 26);
+			k /= 26;
+		}
+		o[5] = 0;
+	};
+	fprintf(fn, "1\t|\t1\t|\tno rank\t|\t\t|\t8\t|\t0\t|\t1\t|\t0\t|\t0\t|\t0\t|\t0\t|\t0\t|\t\t|\n");
+	fprintf(fm, "1\t|\troot\t|\t\t|\tscientific name\t|\n");
+	char a[8], g[8];
+	for (int l = 0; l < 7; l++)
+		for (int64_t k = 0; k < cnt[l]; k++) {
+			const int64_t id = base[l] + k;
+			const int64_t par = l == 0 ? 1 : base[l - 1] + (int64_t)(((unsigned __int128)k * (uint64_t)cnt[l - 1]) / (uint64_t)cnt[l]);
+			fprintf(fn, "%lld\t|\t%lld\t|\t%s\t|\t\t|\t0\t|\t1\t|\t11\t|\t1\t|\t0\t|\t1\t|\t0\t|\t0\t|\t\t|\n",
+				(long long)id, (long long)par, rank_name[l]);
+			alpha5(k, a);
+			if (l < 6) {
+				fprintf(fm, "%lld\t|\t%s%s\t|\t\t|\tscientific name\t|\n", (long long)id, prefix[l], a);
+			} else {
+				alpha5((int64_t)(((unsigned __int128)k * (uint64_t)cnt[5]) / (uint64_t)cnt[6]), g);
+				fprintf(fm, "%lld\t|\tGen%s sp%s\t|\t\t|\tscientific name\t|\n", (long long)id, g, a);
+			}
+		}
+	// `tax_class -n` never finds the last record of names.dmp (ncbitc.c:665): keep it a dummy
+	fprintf(fm, "%lld\t|\tzz sentinel\t|\t\t|\tsynonym\t|\n", (long long)(base[6] + cnt[6] - 1));
+	for (int64_t i = 0; i < c->n_seq; i++)
+		fprintf(fg, "%lld\t%lld\n", (long long)(1000 + i), (long long)(base[6] + i));
+	fclose(fn);
+	fclose(fm);
+	fclose(fg);
+	return 0;
+}
+
+int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs,
+			 int64_t n, char **text, size_t *len)
+{
+	if (!db || !reads || !hits || !recs || !text)
+		return fail(PGX_E_ARG, "pgx_consensus_format: null argument");
+	if (!db->bound)
+		return fail(PGX_E_ARG, "pgx_consensus_format: database is not bound to a taxonomy");
+	std::vector<pgx_hit> hv((size_t)hits->n_hits);
+	PGX_TRY(hits->d_hits.download(hv.data(), hv.size()));
+	Text out;
+	Text cols;
+	for (int64_t r = 0; r < n && r < reads->n; r++) {
+		if (recs[r].hit == -2)
+			continue; // no BLAST lines for this read: the Perl prints nothing for it
+		if (recs[r].hit >= 0) {
+			const pgx_hit &h = hv[(size_t)recs[r].hit];
+			// the line NCBI-taxcollector writes for this hit: id, lineage, then the numeric columns
+			// with the blank in front of a 3-digit bit score eaten by its split (taxcollector:77,148-153)
+			std::string line = reads->name_of(r) + "\t" + db->ids[(size_t)h.subject] + "\t";
+			cols.s.clear();
+			format_hit_columns(h, reads->h_len[(size_t)r], db->n_bases, db->n_seq, cols);
+			line += cols.s;
+			emit_collected(line, db->lineage[(size_t)h.subject], out.s);
+		} else {
+			out.s += "\n";
+		}
+		out.printf("#Matches found: %d\n", recs[r].matches);
+	}
+	*text = out.release_malloc(len);
+	return *text ? 0 : fail(PGX_E_NOMEM, "out of memory");
+}
+
+int pgx_consensus_batch(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *out, int64_t cap)
+{
+	if (!db || !hits || !rdp || !out || cap < hits->n_reads)
+		return fail(PGX_E_ARG, "pgx_consensus_batch: bad argument");
+	PGX_TRY(require_device());
+	DevBuf<pgx_consensus_rec> d_recs;
+	PGX_TRY(d_recs.alloc((size_t)hits->n_reads + 1));
+	PGX_TRY(consensus_device(db, hits, rdp, d_recs.data(), nullptr));
+	return d_recs.download(out, (size_t)hits->n_reads);
+}
+
+int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, const char *o, char **log_text)
+{
+	Text log;
+	auto done = [&](int rc) {
+		if (log_text)
+			*log_text = log.release_malloc(nullptr);
+		return rc;
+	};
+	if (!b || !r || !o)
+		return done(fail(PGX_E_ARG, "consensus: -b, -r and -o are required"));
+	int rc = require_device();
+	if (rc < 0)
+		return done(rc);
+	log.s += "\nLoading input files...\n"; // Consensus:19
+	bool ok;
+	std::string bt = read_text_file(b, &ok);
+	if (!ok) {
+		log.printf("Error: Unable to open %s file.\n", b);
+		return done(fail(PGX_E_IO, "cannot open %s", b));
+	}
+	std::string rt = read_text_file(r, &ok);
+	if (!ok) {
+		log.printf("Error: Unable to open %s file.\n", r);
+		return done(fail(PGX_E_IO, "cannot open %s", r));
+	}
+	if (s_or_null && *s_or_null) {
+		FILE *f = fopen(s_or_null, "r"); // opened and never read (Consensus:40-46)
+		if (!f) {
+			log.printf("Error: Unable to open %s file.\n", s_or_null);
+			return done(fail(PGX_E_IO, "cannot open %s", s_or_null));
+		}
+		fclose(f);
+	}
+	log.printf("%s\n", o); // Consensus:51
+
+	// ---- BLAST(+lineage) table: id, lineage tokens, similarity text per line (Consensus:110-122)
+	std::unordered_map<std::string, uint32_t> tmap;
+	std::vector<std::string> ttext;
+	intern_into(tmap, ttext, "");
+	std::vector<std::string> bline, bid, bsim;
+	std::vector<uint32_t> tok_off(1, 0), tok;
+	std::vector<std::string> tk;
+	for (size_t s = 0; s < bt.size();) {
+		size_t e = bt.find('\n', s);
+		if (e == std::string::npos)
+			e = bt.size();
+		bline.emplace_back(bt, s, e - s);
+		s = e + 1;
+		const std::string &ln = bline.back();
+		// split(/\t\t|\t/): trailing empty fields dropped
+		std::vector<std::string> f;
+		size_t a = 0, i = 0;
+		while (i < ln.size()) {
+			if (ln[i] == '\t') {
+				f.emplace_back(ln, a, i - a);
+				i += (i + 1 < ln.size() && ln[i + 1] == '\t') ? 2 : 1;
+				a = i;
+			} else {
+				i++;
+			}
+		}
+		if (!ln.empty())
+			f.emplace_back(ln, a, ln.size() - a);
+		while (!f.empty() && f.back().empty())
+			f.pop_back();
+		bid.push_back(f.size() > 0 ? f[0] : std::string());
+		bsim.push_back(f.size() > 2 ? f[2] : std::string());
+		lineage_tokens(f.size() > 1 ? f[1] : std::string(), tk);
+		for (auto &t : tk)
+			tok.push_back(intern_into(tmap, ttext, t));
+		tok_off.push_back((uint32_t)tok.size());
+	}
+	std::map<std::string, uint32_t> simrank;
+	build_sim_ranks(bsim, simrank);
+	std::vector<uint32_t> line_sim(bline.size());
+	for (size_t i = 0; i < bline.size(); i++)
+		line_sim[i] = simrank[bsim[i]];
+
+	// ---- RDP lines (Consensus:126-132) and the cursor walk over both files (Consensus:96-240)
+	std::vector<uint32_t> rdp_off(1, 0), rdp_name;
+	std::vector<int8_t> rdp_rank;
+	std::vector<uint32_t> g_first, g_count, g_rdp, g_init;
+	size_t cur = 0;
+	int found = -1; // undef
+	bool sim_is_undef = true;
+	int status = 0;
+	uint32_t rdp_index = 0;
+	for (size_t s = 0; s < rt.size() && status == 0;) {
+		size_t e = rt.find('\n', s);
+		if (e == std::string::npos)
+			e = rt.size();
+		std::string line(rt, s, e - s);
+		s = e + 1;
+		size_t five = line.find("\t\t\t\t\t");
+		std::string rid = five == std::string::npos ? line : line.substr(0, five);
+		if (five != std::string::npos) {
+			std::string rest = line.substr(five + 5);
+			size_t again = rest.find("\t\t\t\t\t");
+			if (again != std::string::npos)
+				rest.resize(again);
+			std::vector<std::string> f;
+			if (!rest.empty()) {
+				for (size_t a = 0; a <= rest.size();) {
+					size_t t = rest.find('\t', a);
+					if (t == std::string::npos)
+						t = rest.size();
+					f.emplace_back(rest, a, t - a);
+					a = t + 1;
+				}
+			}
+			while (!f.empty() && f.back().empty())
+				f.pop_back();
+			for (size_t k = 0; k < f.size(); k += 3) {
+				rdp_name.push_back(intern_into(tmap, ttext, clean_rdp_name(f[k])));
+				rdp_rank.push_back(k + 1 < f.size() ? rdp_rank_index(f[k + 1]) : (int8_t)-1);
+			}
+		}
+		rdp_off.push_back((uint32_t)rdp_name.size());
+		// GETBLAST loop
+		uint32_t first = (uint32_t)cur, count = 0;
+		for (;;) {
+			const bool have = cur < bline.size();
+			const std::string &id = have ? bid[cur] : ttext[0];
+			if (id == rid) {
+				if (!have) {
+					status = fail(PGX_E_REFHANG, "RDP line %u has an empty id after the BLAST table ends: the reference never terminates", rdp_index + 1);
+					break;
+				}
+				if (count == 0)
+					first = (uint32_t)cur;
+				found = 1;
+				count++;
+				cur++;
+				continue;
+			}
+			if (found == 0) {
+				log.printf("not found: %s\t %s\n", id.c_str(), rid.c_str()); // Consensus:217
+				if (!have) {
+					status = fail(PGX_E_REFHANG, "RDP read %s has no BLAST lines at or after the cursor: the reference never terminates (SURVEY 3.5)", rid.c_str());
+					break;
+				}
+				cur++;
+				continue;
+			}
+			if (found == 1) {
+				g_first.push_back(first);
+				g_count.push_back(count);
+				g_rdp.push_back(rdp_index);
+				g_init.push_back(sim_is_undef ? simrank[""] : simrank["0"]);
+				sim_is_undef = false;
+				found = 0;
+			}
+			break;
+		}
+		rdp_index++;
+	}
+
+	// ---- device: agreement counts + arg-max per group
+	const size_t ng = g_first.size();
+	std::vector<pgx_consensus_rec> recs(ng);
+	if (ng) {
+		std::vector<int8_t> tok_rank(ttext.size());
+		for (size_t t = 0; t < ttext.size(); t++)
+			tok_rank[t] = blast_rank_index(ttext[t]);
+		DevBuf<uint32_t> d_first, d_count, d_grdp, d_init, d_toff, d_tok, d_sim, d_roff, d_rname;
+		DevBuf<int8_t> d_trank, d_rrank;
+		DevBuf<pgx_consensus_rec> d_recs;
+		auto up32 = [&](DevBuf<uint32_t> &d, const std::vector<uint32_t> &h) {
+			int q = d.alloc(h.size() ? h.size() : 1);
+			return q < 0 ? q : d.upload(h.data(), h.size());
+		};
+		auto up8 = [&](DevBuf<int8_t> &d, const std::vector<int8_t> &h) {
+			int q = d.alloc(h.size() ? h.size() : 1);
+			return q < 0 ? q : d.upload(h.data(), h.size());
+		};
+		rc = up32(d_first, g_first);
+		if (rc == 0) rc = up32(d_count, g_count);
+		if (rc == 0) rc = up32(d_grdp, g_rdp);
+		if (rc == 0) rc = up32(d_init, g_init);
+		if (rc == 0) rc = up32(d_toff, tok_off);
+		if (rc == 0) rc = up32(d_tok, tok);
+		if (rc == 0) rc = up32(d_sim, line_sim);
+		if (rc == 0) rc = up32(d_roff, rdp_off);
+		if (rc == 0) rc = up32(d_rname, rdp_name);
+		if (rc == 0) rc = up8(d_trank, tok_rank);
+		if (rc == 0) rc = up8(d_rrank, rdp_rank);
+		if (rc == 0) rc = d_recs.alloc(ng);
+		if (rc == 0) {
+			hipLaunchKernelGGL(k_consensus_groups, dim3((unsigned)((ng + 63) / 64)), dim3(64), 0, 0, d_first.data(),
+					   d_count.data(), d_grdp.data(), d_init.data(), (uint32_t)ng, d_toff.data(), d_tok.data(),
+					   d_trank.data(), d_sim.data(), d_roff.data(), d_rname.data(), d_rrank.data(), d_recs.data());
+			if (hipGetLastError() != hipSuccess)
+				rc = fail(PGX_E_NODEVICE, "k_consensus_groups launch failed");
+		}
+		if (rc == 0) rc = d_recs.download(recs.data(), ng);
+		if (rc < 0)
+			return done(rc);
+	}
+	std::string out;
+	for (size_t g = 0; g < ng; g++) {
+		if (recs[g].hit >= 0)
+			out += bline[(size_t)recs[g].hit];
+		out += "\n";
+		char tmp[64];
+		snprintf(tmp, sizeof tmp, "#Matches found: %d\n", recs[g].matches);
+		out += tmp;
+	}
+	int wrc = write_text_file(o, out);
+	if (wrc < 0) {
+		log.printf("Error: Unable to open output file %s.\n", o);
+		return done(wrc);
+	}
+	if (status == 0)
+		log.s += "\nDone!\n"; // Consensus:242
+	return done(status);
+}
+}

@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "bitops.hpp"
+#include "consensus_core.hpp"
 #include "engine.hpp"
 
 namespace pgx {
@@ -485,27 +486,6 @@ __device__ __forceinline__ bool hit_less(const pgx_hit &a, int ba, const pgx_hit
 	return a.send < b.send;
 }
 
-// Perl `gt` on the decimal texts of two non-negative integers (Consensus:191,199)
-__device__ __forceinline__ bool dec_str_gt(uint32_t a, uint32_t b)
-{
-	if (a == b)
-		return false;
-	uint32_t pa = 1, pb = 1; // 10^(digits-1)
-	while (a / pa >= 10)
-		pa *= 10;
-	while (b / pb >= 10)
-		pb *= 10;
-	// compare digit by digit from the most significant
-	while (pa && pb) {
-		uint32_t da = (a / pa) % 10, db = (b / pb) % 10;
-		if (da != db)
-			return da > db;
-		pa /= 10;
-		pb /= 10;
-	}
-	return pa != 0; // the longer text wins when the shorter is its prefix
-}
-
 struct ConsView {
 	const uint32_t *subj_tok_off, *subj_tok; // per subject token ids
 	const int8_t *tok_rank;                  // token id -> index in "0".."6" or -1
@@ -516,20 +496,13 @@ struct ConsView {
 	const uint8_t *rdp_present;
 };
 
-// (rank,name) agreement of one hit with the read's RDP triplets (Consensus:154-184)
-__device__ __forceinline__ uint32_t rank_matches(const ConsView &cv, uint32_t subject, uint32_t r0, uint32_t r1,
-						  uint32_t *ntok_out)
+// (rank,name) agreement of one hit with the read's RDP triplets
+__device__ __forceinline__ uint32_t hit_rank_matches(const ConsView &cv, uint32_t subject, uint32_t r0, uint32_t r1,
+						      uint32_t *ntok_out)
 {
-	const uint32_t t0 = cv.subj_tok_off[subject], t1 = cv.subj_tok_off[subject + 1];
-	*ntok_out = t1 - t0;
-	uint32_t rm = 0;
-	for (uint32_t a = t0; a < t1; a += 2) {
-		const int i1 = cv.tok_rank[cv.subj_tok[a]];
-		const uint32_t name = a + 1 < t1 ? cv.subj_tok[a + 1] : 0u; // undef stringifies to ""
-		for (uint32_t b = r0; b < r1; b++)
-			rm += (name == cv.rdp_name[b]) && (i1 == (int)cv.rdp_rank[b]);
-	}
-	return rm;
+	const uint32_t t0 = cv.subj_tok_off[subject], nt = cv.subj_tok_off[subject + 1] - t0;
+	*ntok_out = nt;
+	return rank_matches(cv.subj_tok + t0, nt, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
 }
 
 constexpr int kSortCap = 256; // hits of one read held in LDS by its wave
@@ -590,7 +563,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 			if (do_consensus) {
 				uint32_t ntok;
 				const uint32_t r0 = cv.rdp_off[r], r1 = cv.rdp_off[r + 1];
-				sw->rm[rank] = rank_matches(cv, (uint32_t)h.subject, r0, r1, &ntok);
+				sw->rm[rank] = hit_rank_matches(cv, (uint32_t)h.subject, r0, r1, &ntok);
 				sw->ntok[rank] = ntok;
 				const int len = h.qend - h.qstart + 1;
 				sw->sim[rank] = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
@@ -605,21 +578,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 			if (cv.rdp_present && !cv.rdp_present[r]) {
 				rec.hit = -2;
 			} else {
-				uint32_t maxrm = 0, maxcnt = 0, cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
-				for (uint32_t k = 0; k < n; k++) {
-					const uint32_t rm = sw->rm[k], c = sw->ntok[k], sim = sw->sim[k];
-					if (dec_str_gt(rm, maxrm)) {
-						maxrm = rm;
-						rec.hit = (int32_t)(o + k);
-						cursim = sim;
-					}
-					if ((dec_str_gt(c, maxcnt) || cursim < sim) && rm == maxrm) {
-						maxcnt = c;
-						rec.hit = (int32_t)(o + k);
-						cursim = sim;
-					}
-				}
-				rec.matches = (int32_t)maxrm;
+				ArgmaxState am;
+				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+				for (uint32_t k = 0; k < n; k++)
+					am.step((int32_t)(o + k), sw->rm[k], sw->ntok[k], sw->sim[k]);
+				rec.hit = am.win;
+				rec.matches = (int32_t)am.maxrm;
 			}
 			recs[r] = rec;
 		}
@@ -693,25 +657,17 @@ __global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint3
 		rec.hit = -2;
 	if (rec.hit == -1) {
 		const uint32_t r0 = cv.rdp_off[r], r1 = cv.rdp_off[r + 1];
-		uint32_t maxrm = 0, maxcnt = 0, cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+		ArgmaxState am;
+		am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
 		for (uint32_t k = 0; k < n; k++) {
 			const pgx_hit h = hits[o + k];
 			uint32_t c;
-			const uint32_t rm = rank_matches(cv, (uint32_t)h.subject, r0, r1, &c);
+			const uint32_t rm = hit_rank_matches(cv, (uint32_t)h.subject, r0, r1, &c);
 			const int len = h.qend - h.qstart + 1;
-			const uint32_t sim = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
-			if (dec_str_gt(rm, maxrm)) {
-				maxrm = rm;
-				rec.hit = (int32_t)(o + k);
-				cursim = sim;
-			}
-			if ((dec_str_gt(c, maxcnt) || cursim < sim) && rm == maxrm) {
-				maxcnt = c;
-				rec.hit = (int32_t)(o + k);
-				cursim = sim;
-			}
+			am.step((int32_t)(o + k), rm, c, cv.simrank_lut[pident_hundredths(len - h.mismatch, len)]);
 		}
-		rec.matches = (int32_t)maxrm;
+		rec.hit = am.win;
+		rec.matches = (int32_t)am.maxrm;
 	}
 	recs[r] = rec;
 }
@@ -896,6 +852,24 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	}
 	g_times.sort_ms = t.stop();
 	g_times.total_ms = total.stop();
+	return 0;
+}
+
+// consensus over an existing hit table (pgx_consensus_batch): one lane per read
+int consensus_device(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *d_out, pgx_stage_times *)
+{
+	if (!db->bound)
+		return fail(PGX_E_ARG, "consensus needs pgx_db_bind_taxonomy() first");
+	if (rdp->n != hits->n_reads)
+		return fail(PGX_E_ARG, "RDP stream and hit table cover different read counts");
+	const uint32_t n = (uint32_t)hits->n_reads;
+	if (n == 0)
+		return 0;
+	const ConsView cv = cons_view(db, rdp);
+	hipLaunchKernelGGL(k_consensus_serial, dim3((n + 63) / 64), dim3(64), 0, 0, hits->d_hits.data(), hits->d_read_off.data(),
+			   hits->d_read_cnt.data(), (const uint32_t *)nullptr, n, cv, d_out);
+	PGX_HIP(hipGetLastError());
+	PGX_HIP(hipDeviceSynchronize());
 	return 0;
 }
 

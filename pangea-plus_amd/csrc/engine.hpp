@@ -53,6 +53,7 @@ struct pgx_reads {
 	bool has_amb = false;
 	std::vector<std::string> names; // empty for synthetic batches
 	std::vector<uint32_t> h_len, h_woff;
+	std::vector<uint64_t> h_fwd; // host copy of the forward strand (file-built batches only)
 	int64_t n_words = 0;
 	int32_t max_len = 0;
 	pgx::DevBuf<uint64_t> d_fwd, d_rc, d_fwd_amb, d_rc_amb;
@@ -80,6 +81,10 @@ namespace pgx {
 
 // seqdb.hip
 int db_upload_and_index(pgx_db *db);
+int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
+			pgx_reads **out);
+int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);
+int db_read_host(const char *prefix, pgx_db **out);
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);
 

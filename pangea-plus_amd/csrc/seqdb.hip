@@ -442,6 +442,111 @@ static int reads_finish(pgx_reads *rd)
 	return 0;
 }
 
+
+// FASTA -> read batch. fold_to_g: every non-ACGT letter is read as G (what the reference's soap does,
+// observed) and `amb_count[i]` receives how many letters of read i were folded.
+int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
+			pgx_reads **out)
+{
+	if (!path || !out)
+		return fail(PGX_E_ARG, "pgx_reads_from_fasta: null argument");
+	PGX_TRY(require_device());
+	bool ok;
+	std::string text = read_text_file(path, &ok);
+	if (!ok)
+		return fail(PGX_E_IO, "cannot open query file %s", path);
+	PackedSet ps;
+	pack_fasta_text(text, ps);
+	int64_t total = (int64_t)ps.headers.size();
+	if (first < 0)
+		first = 0;
+	if (first > total)
+		first = total;
+	if (count < 0 || first + count > total)
+		count = total - first;
+	pgx_reads *rd = new pgx_reads();
+	rd->n = count;
+	rd->first = first;
+	rd->has_amb = ps.any_amb && !fold_to_g;
+	rd->h_len.resize((size_t)count);
+	rd->h_woff.resize((size_t)count + 1);
+	if (amb_count)
+		amb_count->assign((size_t)count, 0);
+	uint64_t nw = 0;
+	for (int64_t i = 0; i < count; i++) {
+		uint64_t L = ps.off[(size_t)(first + i) + 1] - ps.off[(size_t)(first + i)];
+		rd->h_len[(size_t)i] = (uint32_t)L;
+		rd->h_woff[(size_t)i] = (uint32_t)nw;
+		nw += (L + 31) / 32;
+		if ((int32_t)L > rd->max_len)
+			rd->max_len = (int32_t)L;
+		rd->names.push_back(first_word(ps.headers[(size_t)(first + i)]));
+	}
+	rd->h_woff[(size_t)count] = (uint32_t)nw;
+	rd->n_words = (int64_t)nw;
+	// re-pack each read on its own word boundary
+	rd->h_fwd.assign(nw + 2, 0);
+	std::vector<uint64_t> fa(rd->has_amb ? nw + 2 : 0, 0);
+	auto get = [&](const std::vector<uint64_t> &src, uint64_t p) -> uint64_t {
+		return (src[p >> 5] >> (2 * (p & 31))) & 3;
+	};
+	for (int64_t i = 0; i < count; i++) {
+		uint64_t s = ps.off[(size_t)(first + i)], L = rd->h_len[(size_t)i], w0 = rd->h_woff[(size_t)i];
+		for (uint64_t k = 0; k < L; k++) {
+			uint64_t b = get(ps.words, s + k);
+			const bool amb = ps.any_amb && (get(ps.amb, s + k) & 1);
+			if (amb && fold_to_g) {
+				b = 2;
+				if (amb_count)
+					(*amb_count)[(size_t)i]++;
+			}
+			rd->h_fwd[w0 + (k >> 5)] |= b << (2 * (k & 31));
+			if (amb && rd->has_amb)
+				fa[w0 + (k >> 5)] |= 1ull << (2 * (k & 31));
+		}
+	}
+	int rc = rd->d_fwd.alloc((size_t)nw + 2, 0, 0, true);
+	if (rc == 0)
+		rc = rd->d_fwd.upload(rd->h_fwd.data(), (size_t)nw);
+	if (rc == 0 && rd->has_amb) {
+		rc = rd->d_fwd_amb.alloc((size_t)nw + 2, 0, 0, true);
+		if (rc == 0)
+			rc = rd->d_fwd_amb.upload(fa.data(), (size_t)nw);
+	}
+	if (rc == 0)
+		rc = reads_finish(rd);
+	if (rc < 0) {
+		delete rd;
+		return rc;
+	}
+	*out = rd;
+	return 0;
+}
+
+// a database whose ambiguity codes read as G (SOAP mode), built from a file database
+int db_fold_amb_to_g(const pgx_db *src, pgx_db **out)
+{
+	pgx_db *db = new pgx_db();
+	db->n_seq = src->n_seq;
+	db->n_bases = src->n_bases;
+	db->has_amb = false;
+	db->h_seq_off = src->h_seq_off;
+	db->ids = src->ids;
+	db->h_words = src->h_words;
+	if (src->has_amb)
+		for (size_t w = 0; w < db->h_words.size() && w < src->h_amb.size(); w++)
+			db->h_words[w] |= src->h_amb[w] << 1; // flagged bases hold code 0: setting the high bit makes them G
+	int rc = db_upload_and_index(db);
+	if (rc < 0) {
+		delete db;
+		return rc;
+	}
+	*out = db;
+	return 0;
+}
+
+int db_read_host(const char *prefix, pgx_db **out) { return db_read_file(prefix, out); }
+
 } // namespace pgx
 
 std::string pgx_reads::name_of(int64_t i) const
@@ -609,69 +714,7 @@ int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count,
 
 int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_reads **out)
 {
-	if (!path || !out)
-		return fail(PGX_E_ARG, "pgx_reads_from_fasta: null argument");
-	PGX_TRY(require_device());
-	bool ok;
-	std::string text = read_text_file(path, &ok);
-	if (!ok)
-		return fail(PGX_E_IO, "cannot open query file %s", path);
-	PackedSet ps;
-	pack_fasta_text(text, ps);
-	int64_t total = (int64_t)ps.headers.size();
-	if (first < 0)
-		first = 0;
-	if (first > total)
-		first = total;
-	if (count < 0 || first + count > total)
-		count = total - first;
-	pgx_reads *rd = new pgx_reads();
-	rd->n = count;
-	rd->first = first;
-	rd->has_amb = ps.any_amb;
-	rd->h_len.resize((size_t)count);
-	rd->h_woff.resize((size_t)count + 1);
-	uint64_t nw = 0;
-	for (int64_t i = 0; i < count; i++) {
-		uint64_t L = ps.off[(size_t)(first + i) + 1] - ps.off[(size_t)(first + i)];
-		rd->h_len[(size_t)i] = (uint32_t)L;
-		rd->h_woff[(size_t)i] = (uint32_t)nw;
-		nw += (L + 31) / 32;
-		if ((int32_t)L > rd->max_len)
-			rd->max_len = (int32_t)L;
-		rd->names.push_back(first_word(ps.headers[(size_t)(first + i)]));
-	}
-	rd->h_woff[(size_t)count] = (uint32_t)nw;
-	rd->n_words = (int64_t)nw;
-	// re-pack each read on its own word boundary
-	std::vector<uint64_t> fw(nw + 2, 0), fa(ps.any_amb ? nw + 2 : 0, 0);
-	auto get = [&](const std::vector<uint64_t> &src, uint64_t p) -> uint64_t {
-		return (src[p >> 5] >> (2 * (p & 31))) & 3;
-	};
-	for (int64_t i = 0; i < count; i++) {
-		uint64_t s = ps.off[(size_t)(first + i)], L = rd->h_len[(size_t)i], w0 = rd->h_woff[(size_t)i];
-		for (uint64_t k = 0; k < L; k++) {
-			fw[w0 + (k >> 5)] |= get(ps.words, s + k) << (2 * (k & 31));
-			if (ps.any_amb)
-				fa[w0 + (k >> 5)] |= (get(ps.amb, s + k) & 1) << (2 * (k & 31));
-		}
-	}
-	int rc = rd->d_fwd.alloc((size_t)nw + 2, 0, 0, true);
-	if (rc == 0)
-		rc = rd->d_fwd.upload(fw.data(), (size_t)nw);
-	if (rc == 0 && ps.any_amb) {
-		rc = rd->d_fwd_amb.alloc((size_t)nw + 2, 0, 0, true);
-		if (rc == 0)
-			rc = rd->d_fwd_amb.upload(fa.data(), (size_t)nw);
-	}
-	if (rc == 0)
-		rc = reads_finish(rd);
-	if (rc < 0) {
-		delete rd;
-		return rc;
-	}
-	*out = rd;
-	return 0;
+	return pgx::reads_from_fasta_ex(path, first, count, false, nullptr, out);
 }
 
 void pgx_reads_close(pgx_reads *r) { delete r; }

@@ -1,0 +1,91 @@
+"""GPU parity, the whole hot path: classify -> lineage -> consensus fused on the device, against the
+oracle chain (blastn -> taxcollector -> consensus through files) on the same seeded workload."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import run_cmd
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = dict(n_seq=3000, seq_len=500, n_genus=60, read_len=150)
+ARGS = ["--n-seq", "3000", "--seq-len", "500", "--n-genus", "60", "--read-len", "150"]
+N = 4000
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import pangea_plus_amd as pg
+    pg.init(0)
+    return pg
+
+
+@pytest.fixture(scope="module")
+def chain(tmp_path_factory, oracle_bin):
+    d = tmp_path_factory.mktemp("chain")
+    (d / "Tax_class").mkdir()
+    assert run_cmd([oracle_bin, "synth", "db", "--out", str(d / "db.fa")] + ARGS)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "reads", "--out", str(d / "reads.fa"), "--count", str(N)] + ARGS)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "rdp", "--out", str(d / "rdp.tsv"), "--count", str(N)] + ARGS)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "taxdump", "--out", str(d / "Tax_class")] + ARGS)[0] == 0
+    assert run_cmd([oracle_bin, "tax_class", "-c"], cwd=d / "Tax_class")[0] == 0
+    assert run_cmd([oracle_bin, "blastn", "-query", str(d / "reads.fa"), "-db", str(d / "db.fa"), "-outfmt", "6", "-out",
+                    str(d / "hits.tsv"), "-num_threads", "8"], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "taxcollector", "-f", str(d / "hits.tsv"), "-o", str(d / "hits_class.tsv"), "-d",
+                    str(d / "Tax_class")], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "consensus", "-b", str(d / "hits_class.tsv"), "-r", str(d / "rdp.tsv"), "-o",
+                    str(d / "consensus.txt")], timeout=600)[0] == 0
+    return d
+
+
+def test_fused_pipeline_equals_oracle_chain(pg, chain):
+    from pangea_plus_amd import _capi
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    tax = pg.TaxDb.open(str(chain / "Tax_class"))
+    db.bind_taxonomy(tax)
+    assert db.subject_lineage(0) == "[0]Domaaaaa;[1]Phyaaaaa;[2]Clsaaaaa;[3]Ordaaaaa;[4]Famaaaaa;[5]Genaaaaa;[6]Genaaaaa_spaaaaa;"
+    reads = pg.Reads.from_synth(cfg, 0, N)
+    rdp = pg.Rdp.from_synth(cfg, 0, N, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    assert hits.format(db, reads) == (chain / "hits.tsv").read_bytes()
+    text = _capi.consensus_format(db, reads, hits, recs)
+    want = (chain / "consensus.txt").read_bytes()
+    assert len(want) > 100000
+    assert text == want
+    # the same through the file-format RDP stream, and consensus over an existing hit table
+    rdp2 = pg.Rdp.from_file(str(chain / "rdp.tsv"), reads, db)
+    recs2 = np.zeros(N, dtype=_capi.REC_DTYPE)
+    _capi._check(pg.lib().pgx_consensus_batch(db.ptr, hits.ptr, rdp2.ptr, recs2.ctypes.data, N))
+    assert (recs2 == recs).all()
+
+
+def test_file_verbs_chain_equals_oracle_chain(pg, chain, tmp_path):
+    # the three reference command lines, run one after the other on files
+    pg.makeblastdb(str(chain / "db.fa"), str(tmp_path / "db"))
+    pg.blastn(str(chain / "reads.fa"), str(tmp_path / "db"), str(tmp_path / "hits.tsv"))
+    assert (tmp_path / "hits.tsv").read_bytes() == (chain / "hits.tsv").read_bytes()
+    pg.taxcollector(str(tmp_path / "hits.tsv"), str(tmp_path / "hits_class.tsv"), taxdir=str(chain / "Tax_class"))
+    assert (tmp_path / "hits_class.tsv").read_bytes() == (chain / "hits_class.tsv").read_bytes()
+    pg.consensus(str(tmp_path / "hits_class.tsv"), str(chain / "rdp.tsv"), str(tmp_path / "consensus.txt"))
+    assert (tmp_path / "consensus.txt").read_bytes() == (chain / "consensus.txt").read_bytes()
+
+
+def test_pident_rounding_equals_printf(pg):
+    # the device orders hits by the TEXT of pident; its hundredths must be what printf("%.2f") prints
+    lib = ctypes.CDLL(None)
+    bad = 0
+    for L in list(range(28, 400)) + [1000, 1400, 1999]:
+        for m in range(max(1, L - 60), L + 1):
+            want = int(round(float("%.2f" % (100.0 * m / L)) * 100))
+            q, r = divmod(10000 * m, L)
+            got = q + 1 if 2 * r > L else q
+            if 2 * r == L:
+                d = 100.0 * m / L
+                import math
+                s = math.fma(d, 200.0, -(2 * q + 1)) if hasattr(math, "fma") else (d * 200.0 - (2 * q + 1))
+                got = q + 1 if s > 0 else (q if s < 0 else q + (q & 1))
+            bad += got != want
+    assert bad == 0
