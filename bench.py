@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — classified reads/s of the classify -> lineage -> consensus hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU via torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic 150-bp reads
+(1 % substitutions, either strand) against the synthetic 1 Gbp 16S-like database (666 667 x 1 500 bp,
+20 000 genus ancestors, 3 % divergence) with its 7-rank synthetic taxonomy and a synthetic RDP stream.
+One STEP = one pass of the whole hot path (seed + extend, grouping, -outfmt 6 ordering, per-subject
+lineage, consensus arg-max) over one batch of 10 M reads per GPU; reads, RDP assignments, database,
+seed index and taxonomy are resident in HBM when the timed region starts, results stay in HBM.
+Multi-GPU: reads are sharded (weak scaling, no data-path collective); the database + index are built on
+rank 0 and broadcast ONCE over RCCL before the timed region.
+
+Prints one JSON line (rank 0).  `roofline` is for the dominant kernel k_seed_extend: algorithmic bytes
+per launch / its HIP-event duration, against 8 TB/s.  `cpu_baseline` is the
+oracle's CPU restatement of the same chain ("port") on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes(n_reads, st, read_len):
+    """bytes k_seed_extend must move for one launch, from its own counters."""
+    words = (read_len + 31) // 32
+    per_read = 2 * 8 * words + 8            # both packed strands + length/offset
+    per_probe = 8                            # one bucket_off pair
+    per_posting = 4
+    per_run = 4 + 8 + 8 * (words + 1)        # blk_subj + seq_off pair + the database window of the diagonal
+    per_hit = 32
+    return (n_reads * per_read + st.probes * per_probe + st.postings * per_posting + st.candidates * per_run
+            + st.hits * per_hit + n_reads * 4)
+
+
+def cpu_baseline(cfg, taxdir, sample):
+    """The oracle chain (test infrastructure) timed on this box's host cores."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    so = os.path.join(odir, "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", odir, "liboracle.so"], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+
+    class OCfg(C.Structure):
+        _fields_ = [("seed", C.c_uint64), ("n_seq", C.c_int64), ("seq_len", C.c_int32), ("n_genus", C.c_int64),
+                    ("read_seed", C.c_uint64), ("read_len", C.c_int32)]
+
+    class Res(C.Structure):
+        _fields_ = [("gen_s", C.c_double), ("search_s", C.c_double), ("format_s", C.c_double),
+                    ("taxcollect_s", C.c_double), ("consensus_s", C.c_double), ("reads", C.c_int64), ("hits", C.c_int64),
+                    ("recs", C.c_int64), ("threads", C.c_int32)]
+    oc = OCfg(cfg.seed, cfg.n_seq, cfg.seq_len, cfg.n_genus, cfg.read_seed, cfg.read_len)
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    lib.o_bench_chain.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char_p, C.c_void_p]
+    res = Res()
+    rc = lib.o_bench_chain(C.byref(oc), 0, sample, threads, taxdir.encode(), C.byref(res))
+    if rc != 0:
+        return None
+    t = res.search_s + res.format_s + res.taxcollect_s + res.consensus_s
+    return {"value": sample / t, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "%d reads of the same stream vs the full database: search %.1fs (%d threads) + format %.1fs + "
+                      "taxcollector %.1fs + consensus %.1fs (single thread)" % (
+                          sample, res.search_s, threads, res.format_s, res.taxcollect_s, res.consensus_s)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-seq", type=int, default=666667)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import pangea_plus_amd as pg
+    from pangea_plus_amd import _capi
+    pg.init(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = pg.SynthCfg.default()
+    if args.n_seq != cfg.n_seq:  # smaller database for quick functional runs
+        cfg.n_genus = max(1, cfg.n_genus * args.n_seq // cfg.n_seq)
+        cfg.n_seq = args.n_seq
+    tmp = tempfile.mkdtemp(prefix="pgx_bench_%d_" % rank)
+    try:
+        # ---- setup (untimed): taxonomy, database + seed index, one-off broadcast, binding, batches
+        _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), tmp.encode()))
+        pg.TaxDb.create(tmp)
+        tax = pg.TaxDb.open(tmp)
+        t0 = time.time()
+        if rank == 0:
+            db = pg.Db.from_synth(cfg)
+        t_index = time.time() - t0
+        t_bcast = 0.0
+        if world > 1:
+            shape = [db.shape() if rank == 0 else None]
+            dist.broadcast_object_list(shape, src=0)
+            if rank != 0:
+                db = pg.Db.alloc_like(shape[0])
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for name, view in db.device_arrays():
+                t = torch.as_tensor(view, device=dev)  # zero-copy alias of library-owned HBM
+                dist.broadcast(t, src=0)
+            torch.cuda.synchronize()
+            t_bcast = time.time() - t0
+            if rank != 0:
+                db.finish_import()
+        db.bind_taxonomy(tax)
+        B = args.reads
+        batches = []
+        for s in range(args.warmup + args.steps):
+            first = (s * world + rank) * B
+            reads = pg.Reads.from_synth(cfg, first, B)
+            rdp = pg.Rdp.from_synth(cfg, first, B, db)
+            batches.append((reads, rdp))
+
+        def step(i):
+            reads, rdp = batches[i]
+            _capi.classify_consensus(db, reads, rdp, want_records=False, want_hits=False)
+            return _capi.stage_times()
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        kernel_ms, alg_bytes, stages = 0.0, 0, []
+        for i in range(args.warmup, args.warmup + args.steps):
+            st = step(i)
+            kernel_ms += st.seed_extend_ms
+            alg_bytes += algorithmic_bytes(B, st, cfg.read_len)
+            stages.append(st)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+
+        if rank == 0:
+            last = stages[-1]
+            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("k_seed_extend_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out = {
+                "metric": "classified reads/sec (+ HBM GB/s fraction), 150 bp vs 1 Gbp db, 1/2/4/8 GPU",
+                "value": world * B * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u64 (2-bit packed bases, integer scores)",
+                "data": "synthetic",
+                "config": {"workload": "10M synthetic 150 bp reads vs 1 Gbp nt-slice, 1 GPU, full classify->tax_class->consensus"
+                                       if (B == 10_000_000 and cfg.n_seq == 666667) else "reduced functional run",
+                           "reads_per_gpu_per_step": B, "db_bases": int(cfg.n_seq) * int(cfg.seq_len), "db_seqs": int(cfg.n_seq),
+                           "read_len": int(cfg.read_len), "parallelism": "read-sharded x%d, index broadcast once over RCCL" % world,
+                           "spec": "pgx-blastn v1"},
+                "roofline": {"bound": "hbm", "kernel": "k_seed_extend", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "alg_bytes_per_launch": alg_bytes / args.steps, "kernel_ms_per_launch": kernel_ms / args.steps},
+                "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "group": last.group_ms,
+                                        "sort_consensus": last.sort_ms, "total": last.total_ms},
+                "per_read_last_step": {"probes": last.probes / B, "postings": last.postings / B,
+                                       "seed_runs": last.candidates / B, "hits": last.hits / B},
+                "setup_s": {"db_generate_and_index": t_index, "index_broadcast": t_bcast},
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg, tmp, args.cpu_sample)
+            else:
+                out["cpu_baseline"] = None
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

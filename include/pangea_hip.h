@@ -73,6 +73,7 @@ typedef struct {
 	int64_t n_seq, n_bases;
 	int32_t has_amb, index_bits;
 	int64_t n_postings;
+	int32_t synthetic_ids; /* subject ids are the generator's "gi|<1000+i>|syn|S<i>|" */
 } pgx_db_shape;
 int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out);
 int pgx_db_alloc_like(const pgx_db_shape *shape, pgx_db **out);

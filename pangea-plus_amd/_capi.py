@@ -54,7 +54,7 @@ class _DevArray(C.Structure):
 
 class _DbShape(C.Structure):
     _fields_ = [("n_seq", C.c_int64), ("n_bases", C.c_int64), ("has_amb", C.c_int32), ("index_bits", C.c_int32),
-                ("n_postings", C.c_int64)]
+                ("n_postings", C.c_int64), ("synthetic_ids", C.c_int32)]
 
 
 class _BlastnOpts(C.Structure):
@@ -229,7 +229,7 @@ class Db(_Handle):
     def shape(self):
         s = _DbShape()
         _check(lib().pgx_db_get_shape(self.ptr, C.byref(s)))
-        return (s.n_seq, s.n_bases, s.has_amb, s.index_bits, s.n_postings)
+        return (s.n_seq, s.n_bases, s.has_amb, s.index_bits, s.n_postings, s.synthetic_ids)
 
     def device_arrays(self):
         arr = (_DevArray * 16)()

@@ -125,7 +125,7 @@ __device__ __forceinline__ void emit_hit(WaveStage *st, pgx_hit *hits, unsigned 
 template <bool AMB>
 __device__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read, int strand,
 				  int qp, uint32_t p, WaveStage *st, pgx_hit *hits, unsigned long long cap,
-				  unsigned long long *hit_count)
+				  unsigned long long *hit_count, unsigned long long &n_runs)
 {
 	uint32_t s = db.blk_subj[p >> 6];
 	while (db.seq_off[s + 1] <= p)
@@ -154,6 +154,7 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 	const int run_start = lm + 1;
 	if (re - run_start < kWord)
 		return;
+	n_runs++; // a >= 28 exact run reached through its left-most probe
 	// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
 	int pos = D.lo;
 	while (pos < run_start) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	__shared__ WaveStage s_stage[kWavesPerBlock];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveStage *st = &s_stage[wave];
-	unsigned long long n_probe = 0, n_post = 0;
+	unsigned long long n_probe = 0, n_post = 0, n_runs = 0;
 
 	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
 		const int L = (int)rd.len[r];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 						const uint64_t *a = o_strand ? rd.rc_amb : rd.fwd_amb;
 						ra = a ? a + w0 : nullptr;
 					}
-					process_candidate<AMB>(db, rw, ra, L, r, o_strand, o_qpos, p, st, hits, cap, &counters[0]);
+					process_candidate<AMB>(db, rw, ra, L, r, o_strand, o_qpos, p, st, hits, cap, &counters[0], n_runs);
 				}
 				lds_fence();
 				// flush the stage when it is more than half full (wave-uniform decision)
@@ -364,10 +365,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	for (int d = 32; d >= 1; d >>= 1) {
 		n_probe += __shfl_down(n_probe, d);
 		n_post += __shfl_down(n_post, d);
+		n_runs += __shfl_down(n_runs, d);
 	}
 	if (lane == 0) {
 		atomicAdd(&counters[1], n_probe);
 		atomicAdd(&counters[2], n_post);
+		atomicAdd(&counters[3], n_runs);
 	}
 }
 
@@ -746,6 +749,17 @@ struct EventTimer {
 	}
 };
 
+// Buffers that persist across pipeline calls: the steady state of a batch loop allocates nothing.
+struct Workspace {
+	DevBuf<unsigned long long> counters;
+	DevBuf<pgx_hit> scratch;
+	DevBuf<uint32_t> partial, cursor, big_list, big_count;
+	DevBuf<pgx_consensus_rec> recs;
+	pgx_hits hits; // used when the caller does not keep the hit table
+	uint64_t hit_cap_hint = 0;
+};
+static Workspace g_ws;
+
 // search + group + sort (+ consensus when rdp != null). d_recs: device array of n_reads records.
 int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out, pgx_consensus_rec *d_recs)
 {
@@ -757,10 +771,10 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	memset(&g_times, 0, sizeof g_times);
 	const uint64_t n = (uint64_t)rd->n;
 	out->n_reads = rd->n;
-	PGX_TRY(out->d_read_cnt.alloc(n + 1, 0, 0, true));
-	PGX_TRY(out->d_read_off.alloc(n + 1, 0, 0, true));
-	DevBuf<unsigned long long> counters;
-	PGX_TRY(counters.alloc(4, 0, 0, true));
+	PGX_TRY(out->d_read_cnt.ensure(n + 1));
+	PGX_TRY(out->d_read_off.ensure(n + 1));
+	DevBuf<unsigned long long> &counters = g_ws.counters;
+	PGX_TRY(counters.ensure(4));
 	if (n == 0) {
 		out->n_hits = 0;
 		return 0;
@@ -773,11 +787,12 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	total.start();
 
 	// seed + extend into a scratch table; grow and repeat if the guess was too small
-	uint64_t cap = std::max<uint64_t>(n * 48, 1 << 16);
-	DevBuf<pgx_hit> scratch;
+	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(n * 40, 1 << 16), g_ws.hit_cap_hint);
+	DevBuf<pgx_hit> &scratch = g_ws.scratch;
 	unsigned long long h_cnt[4];
 	for (;;) {
-		PGX_TRY(scratch.alloc(cap));
+		PGX_TRY(scratch.ensure(cap));
+		cap = scratch.n;
 		PGX_HIP(hipMemsetAsync(counters.data(), 0, 4 * sizeof(unsigned long long), 0));
 		t.start();
 		if (amb)
@@ -794,10 +809,12 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		cap = h_cnt[0] + h_cnt[0] / 8;
 	}
 	const uint64_t H = h_cnt[0];
+	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, H + H / 16);
 	out->n_hits = (int64_t)H;
 	g_times.hits = (int64_t)H;
 	g_times.probes = (int64_t)h_cnt[1];
 	g_times.postings = (int64_t)h_cnt[2];
+	g_times.candidates = (int64_t)h_cnt[3];
 	if (H >= (1ull << 32))
 		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
 			    (unsigned long long)H);
@@ -805,15 +822,16 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	// group by read: exclusive scan of the per-read counts, then scatter
 	t.start();
 	const uint32_t n_part = (uint32_t)((n + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
-	DevBuf<uint32_t> partial, cursor;
-	PGX_TRY(partial.alloc(n_part));
-	PGX_TRY(cursor.alloc(n, 0, 0, true));
+	DevBuf<uint32_t> &partial = g_ws.partial, &cursor = g_ws.cursor;
+	PGX_TRY(partial.ensure(n_part));
+	PGX_TRY(cursor.ensure(n));
+	PGX_HIP(hipMemsetAsync(cursor.data(), 0, n * sizeof(uint32_t), 0));
 	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data());
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, 0, partial.data(), n_part);
 	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data(),
 			   out->d_read_off.data());
 	PGX_HIP(hipGetLastError());
-	PGX_TRY(out->d_hits.alloc(H ? H : 1));
+	PGX_TRY(out->d_hits.ensure(H ? H : 1));
 	if (H) {
 		const int g2 = (int)std::min<uint64_t>((H + 255) / 256, 256ull * 16);
 		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, scratch.data(), H, out->d_read_off.data(),
@@ -824,9 +842,10 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 
 	// per-read order (+ consensus)
 	t.start();
-	DevBuf<uint32_t> big_list, big_count;
-	PGX_TRY(big_list.alloc(n));
-	PGX_TRY(big_count.alloc(1, 0, 0, true));
+	DevBuf<uint32_t> &big_list = g_ws.big_list, &big_count = g_ws.big_count;
+	PGX_TRY(big_list.ensure(n));
+	PGX_TRY(big_count.ensure(1));
+	PGX_HIP(hipMemsetAsync(big_count.data(), 0, sizeof(uint32_t), 0));
 	const ConsView cv = cons_view(db, rdp);
 	const size_t lds = sizeof(SortWave) * kWavesPerBlock;
 	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), lds, 0, out->d_hits.data(),
@@ -898,20 +917,21 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 {
 	if (!db || !reads || !rdp)
 		return fail(PGX_E_ARG, "pgx_classify_consensus: null argument");
-	DevBuf<pgx_consensus_rec> recs;
-	PGX_TRY(recs.alloc((size_t)reads->n + 1));
-	pgx_hits *h = new pgx_hits();
-	int rc = search_pipeline(db, reads, rdp, h, recs.data());
+	PGX_TRY(g_ws.recs.ensure((size_t)reads->n + 1));
+	pgx_hits *h = hits_out ? new pgx_hits() : &g_ws.hits;
+	int rc = search_pipeline(db, reads, rdp, h, g_ws.recs.data());
 	if (rc == 0 && out) {
 		if (cap < reads->n)
 			rc = fail(PGX_E_ARG, "record buffer too small");
 		else
-			rc = recs.download(out, (size_t)reads->n);
+			rc = g_ws.recs.download(out, (size_t)reads->n);
 	}
-	if (rc < 0 || !hits_out)
-		delete h;
-	else
-		*hits_out = h;
+	if (hits_out) {
+		if (rc < 0)
+			delete h;
+		else
+			*hits_out = h;
+	}
 	return rc;
 }
 

@@ -73,6 +73,13 @@ template <typename T> struct DevBuf {
 		}
 		return 0;
 	}
+	// grow-only variant for workspaces that live across calls (no hipMalloc in the steady state)
+	int ensure(size_t count)
+	{
+		if (base && count <= n && pad == 0)
+			return 0;
+		return alloc(count + count / 8);
+	}
 	T *data() const { return base ? base + pad : nullptr; }
 	size_t bytes() const { return n * sizeof(T); }
 	int upload(const T *host, size_t count)

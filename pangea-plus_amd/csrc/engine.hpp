@@ -19,6 +19,7 @@
 struct pgx_db {
 	int64_t n_seq = 0, n_bases = 0;
 	bool has_amb = false;
+	bool synthetic_ids = false;
 	std::vector<uint32_t> h_seq_off;
 	std::vector<std::string> ids;
 	// host copy of the packed bases is kept only for file-built databases (SOAP row formatting)

@@ -236,6 +236,17 @@ int db_upload_and_index(pgx_db *db)
 	return db_build_index(db);
 }
 
+static void synth_ids(pgx_db *db)
+{
+	db->ids.clear();
+	db->ids.reserve((size_t)db->n_seq);
+	char buf[64];
+	for (int64_t i = 0; i < db->n_seq; i++) {
+		snprintf(buf, sizeof buf, "gi|%lld|syn|S%lld|", (long long)(1000 + i), (long long)i);
+		db->ids.emplace_back(buf);
+	}
+}
+
 static int db_from_packed(PackedSet &ps, pgx_db **out)
 {
 	pgx_db *db = new pgx_db();
@@ -650,12 +661,8 @@ int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out)
 	db->h_seq_off.resize((size_t)db->n_seq + 1);
 	for (int64_t i = 0; i <= db->n_seq; i++)
 		db->h_seq_off[(size_t)i] = (uint32_t)(i * cfg->seq_len);
-	db->ids.reserve((size_t)db->n_seq);
-	char buf[64];
-	for (int64_t i = 0; i < db->n_seq; i++) {
-		snprintf(buf, sizeof buf, "gi|%lld|syn|S%lld|", (long long)(1000 + i), (long long)i);
-		db->ids.emplace_back(buf);
-	}
+	db->synthetic_ids = true;
+	synth_ids(db);
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
 	int rc = db->d_words.alloc(nw, 1, 2, true);
 	if (rc == 0) {
@@ -749,6 +756,7 @@ int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out)
 	out->has_amb = db->has_amb;
 	out->index_bits = db->index_bits;
 	out->n_postings = db->n_postings;
+	out->synthetic_ids = db->synthetic_ids;
 	return 0;
 }
 
@@ -786,6 +794,7 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 	db->has_amb = s->has_amb != 0;
 	db->index_bits = s->index_bits;
 	db->n_postings = s->n_postings;
+	db->synthetic_ids = s->synthetic_ids != 0;
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
 	int rc = db->d_words.alloc(nw, 1, 2, true);
 	if (rc == 0 && db->has_amb)
@@ -812,6 +821,10 @@ int pgx_db_finish_import(pgx_db *db)
 		return fail(PGX_E_ARG, "pgx_db_finish_import: null argument");
 	db->h_seq_off.resize((size_t)db->n_seq + 1);
 	PGX_TRY(db->d_seq_off.download(db->h_seq_off.data(), (size_t)db->n_seq + 1));
+	if (db->synthetic_ids)
+		pgx::synth_ids(db);
+	else if (db->ids.empty())
+		return fail(PGX_E_ARG, "imported database has no subject ids");
 	return 0;
 }
 }
