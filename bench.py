@@ -92,6 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda:%d" % local_rank)  # torch's HIP context first (RCCL needs it)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import pangea_plus_amd as pg
