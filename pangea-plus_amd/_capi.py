@@ -1,6 +1,7 @@
 """ctypes binding of include/pangea_hip.h and the Python mirror of the reference's CLI verbs."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -24,6 +25,14 @@ def lib():
         if not os.path.exists(lib_path):
             raise PangeaError(-3, "libpangea_hip.so is not built (run `python pangea-plus_amd/build.py`); "
                                   "this package has no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own HIP runtime; whichever runtime is loaded first owns the GPU for
+        # the process, so when torch is installed let it load first and bind this library to the same one
+        # (bench.py and the broadcast path use torch tensors that alias this library's HBM).
+        if "torch" not in sys.modules and not os.environ.get("PGX_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(lib_path)
         _declare(_lib)
     return _lib

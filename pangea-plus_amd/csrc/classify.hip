@@ -64,68 +64,140 @@ template <bool AMB> __device__ __forceinline__ uint64_t mmw(const Diag &D, int w
 	return m;
 }
 
-// smallest flagged position >= pos, or hi
-template <bool AMB> __device__ __forceinline__ int first_mm_ge(const Diag &D, int pos)
+// even bits of x packed into the low 32 bits
+__device__ __forceinline__ uint64_t compress_even(uint64_t x)
 {
-	if (pos >= D.hi)
-		return D.hi;
-	int w = pos >> 5;
-	uint64_t m = mmw<AMB>(D, w) & ~((1ull << (2 * (pos & 31))) - 1);
-	while (!m) {
-		w++;
-		if (32 * w >= D.hi)
-			return D.hi;
-		m = mmw<AMB>(D, w);
-	}
-	int r = 32 * w + ((__ffsll((unsigned long long)m) - 1) >> 1);
-	return r < D.hi ? r : D.hi;
+	x = (x | (x >> 1)) & 0x3333333333333333ull;
+	x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+	return x;
 }
 
-// largest flagged position < pos, or lo-1
-template <bool AMB> __device__ __forceinline__ int last_mm_lt(const Diag &D, int pos)
-{
-	if (pos <= D.lo)
-		return D.lo - 1;
-	int q = pos - 1, w = q >> 5, bit = q & 31;
-	uint64_t keep = bit == 31 ? ~0ull : ((1ull << (2 * bit + 2)) - 1);
-	uint64_t m = mmw<AMB>(D, w) & keep;
-	while (!m) {
-		if (32 * w <= D.lo)
-			return D.lo - 1;
-		w--;
-		m = mmw<AMB>(D, w);
+// Mismatch flags of one diagonal, two forms with the same interface:
+//   DenseMask  reads of <= 192 bases: the whole diagonal as 3 x 64 one-bit flags in registers, built
+//              once (5 read words + 5 database windows for a 150-bp read); every scan is bit logic
+//   LazyMask   any length: 32-base words rebuilt on demand (loads served by L1/L2)
+template <bool AMB> struct DenseMask {
+	uint64_t m0, m1, m2;
+	int lo, hi;
+	__device__ __forceinline__ void build(const Diag &D)
+	{
+		lo = D.lo;
+		hi = D.hi;
+		uint64_t d[6];
+#pragma unroll
+		for (int w = 0; w < 6; w++)
+			d[w] = compress_even(mmw<AMB>(D, w));
+		m0 = d[0] | (d[1] << 32);
+		m1 = d[2] | (d[3] << 32);
+		m2 = d[4] | (d[5] << 32);
 	}
-	int r = 32 * w + ((63 - __clzll((long long)m)) >> 1);
-	return r >= D.lo ? r : D.lo - 1;
-}
-
-constexpr int kStage = 128; // hits staged in LDS per wave between flushes
-constexpr int kWavesPerBlock = 4;
-
-struct WaveStage {
-	pgx_hit hit[kStage];
-	unsigned int n;      // staged
-	unsigned int direct; // emitted straight to HBM because the stage was full
+	// smallest flagged position >= pos, or hi
+	__device__ __forceinline__ int first_ge(int pos) const
+	{
+		if (pos >= hi)
+			return hi;
+		uint64_t a0 = pos < 64 ? m0 & (~0ull << pos) : 0ull;
+		uint64_t a1 = pos < 64 ? m1 : (pos < 128 ? m1 & (~0ull << (pos - 64)) : 0ull);
+		uint64_t a2 = pos < 128 ? m2 : m2 & (~0ull << (pos - 128));
+		int r = a0 ? __ffsll((unsigned long long)a0) - 1
+			   : (a1 ? 63 + __ffsll((unsigned long long)a1) : (a2 ? 127 + __ffsll((unsigned long long)a2) : 192));
+		return r < hi ? r : hi;
+	}
+	// largest flagged position < pos, or lo-1
+	__device__ __forceinline__ int last_lt(int pos) const
+	{
+		if (pos <= lo)
+			return lo - 1;
+		uint64_t b0 = pos >= 64 ? m0 : m0 & ((1ull << pos) - 1);
+		uint64_t b1 = pos >= 128 ? m1 : (pos > 64 ? m1 & ((1ull << (pos - 64)) - 1) : 0ull);
+		uint64_t b2 = pos >= 192 ? m2 : (pos > 128 ? m2 & ((1ull << (pos - 128)) - 1) : 0ull);
+		int r = b2 ? 191 - __clzll((long long)b2) : (b1 ? 127 - __clzll((long long)b1) : (b0 ? 63 - __clzll((long long)b0) : -1));
+		return r >= lo ? r : lo - 1;
+	}
 };
 
-__device__ __forceinline__ void emit_hit(WaveStage *st, pgx_hit *hits, unsigned long long cap,
-					  unsigned long long *hit_count, const pgx_hit &h)
+template <bool AMB> struct LazyMask {
+	Diag D;
+	int lo, hi;
+	__device__ __forceinline__ void build(const Diag &d)
+	{
+		D = d;
+		lo = d.lo;
+		hi = d.hi;
+	}
+	__device__ __forceinline__ int first_ge(int pos) const
+	{
+		if (pos >= hi)
+			return hi;
+		int w = pos >> 5;
+		uint64_t m = mmw<AMB>(D, w) & ~((1ull << (2 * (pos & 31))) - 1);
+		while (!m) {
+			w++;
+			if (32 * w >= hi)
+				return hi;
+			m = mmw<AMB>(D, w);
+		}
+		int r = 32 * w + ((__ffsll((unsigned long long)m) - 1) >> 1);
+		return r < hi ? r : hi;
+	}
+	__device__ __forceinline__ int last_lt(int pos) const
+	{
+		if (pos <= lo)
+			return lo - 1;
+		int q = pos - 1, w = q >> 5, bit = q & 31;
+		uint64_t keep = bit == 31 ? ~0ull : ((1ull << (2 * bit + 2)) - 1);
+		uint64_t m = mmw<AMB>(D, w) & keep;
+		while (!m) {
+			if (32 * w <= lo)
+				return lo - 1;
+			w--;
+			m = mmw<AMB>(D, w);
+		}
+		int r = 32 * w + ((63 - __clzll((long long)m)) >> 1);
+		return r >= lo ? r : lo - 1;
+	}
+};
+
+constexpr int kStage = 128; // hits staged in LDS per wave between flushes
+constexpr int kQueue = 128; // candidate queue per wave (filled 64 at a time, drained at >= 64)
+constexpr int kWavesPerBlock = 4;
+constexpr uint32_t kFragmented = 0xFFFFFFFFu;
+
+struct WaveLds {
+	pgx_hit hit[kStage];
+	uint32_t qp[kQueue], qmeta[kQueue]; // queued candidates: posting, strand << 31 | tested << 30 | qpos
+	unsigned int n;                      // staged hits
+	unsigned int direct;                 // hits that found the stage full and went straight to the overflow table
+};
+
+struct OutView {
+	pgx_hit *main, *ovf;
+	unsigned long long main_cap, ovf_cap;
+	unsigned long long *counters; // [0] main hits, [1] probes, [2] postings, [3] seed runs, [4] overflow hits
+};
+
+__device__ __forceinline__ void emit_hit(WaveLds *st, const OutView &ov, const pgx_hit &h)
 {
 	unsigned int slot = atomicAdd(&st->n, 1u);
 	if (slot < (unsigned)kStage) {
 		st->hit[slot] = h;
 	} else {
 		atomicAdd(&st->direct, 1u);
-		unsigned long long g = atomicAdd(hit_count, 1ull);
-		if (g < cap)
-			hits[g] = h;
+		unsigned long long g = atomicAdd(&ov.counters[4], 1ull);
+		if (g < ov.ovf_cap)
+			ov.ovf[g] = h;
 	}
 }
 
-template <bool AMB>
-__device__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read, int strand,
-				  int qp, uint32_t p, WaveStage *st, pgx_hit *hits, unsigned long long cap,
-				  unsigned long long *hit_count, unsigned long long &n_runs)
+// One candidate = one (strand, probe position, posting).  `tested` says the index already proved that
+// this probe is the left-most one of its exact run (test 1 below).
+template <bool AMB, class Mask>
+__device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read,
+						   int strand, int qp, uint32_t p, bool tested, WaveLds *st, const OutView &ov,
+						   unsigned long long &n_runs)
 {
 	uint32_t s = db.blk_subj[p >> 6];
 	while (db.seq_off[s + 1] <= p)
@@ -142,13 +214,15 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 	int64_t lo64 = (int64_t)s_start - D.dstart, hi64 = (int64_t)s_end - D.dstart;
 	D.lo = lo64 > 0 ? (int)lo64 : 0;
 	D.hi = hi64 < L ? (int)hi64 : L;
+	Mask M;
+	M.build(D);
 
 	// (1) only the left-most probe inside an exact run reports that run
-	const int lm = last_mm_lt<AMB>(D, qp);
-	if (qp >= kProbeStride && lm < qp - kProbeStride)
+	const int lm = M.last_lt(qp);
+	if (!tested && qp >= kProbeStride && lm < qp - kProbeStride)
 		return;
 	// (2) the probe 16-mer itself must match (bucket collisions, ambiguity, boundaries)
-	const int re = first_mm_ge<AMB>(D, qp);
+	const int re = M.first_ge(qp);
 	if (re < qp + kSeedK)
 		return;
 	const int run_start = lm + 1;
@@ -158,16 +232,16 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 	// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
 	int pos = D.lo;
 	while (pos < run_start) {
-		int m1 = first_mm_ge<AMB>(D, pos);
+		int m1 = M.first_ge(pos);
 		if (m1 - pos >= kWord)
 			return;
 		pos = m1 + 1;
 	}
-	// (4) spec S3: seeds left to right, X-drop extension on the mismatch masks
+	// (4) spec S3: seeds left to right, X-drop extension on the mismatch flags
 	int covered = D.lo;
 	pos = run_start;
 	while (pos < D.hi) {
-		const int e = first_mm_ge<AMB>(D, pos);
+		const int e = M.first_ge(pos);
 		const int len = e - pos;
 		if (len >= kWord && pos >= covered) {
 			int best = 0, cur = 0, bl = pos, nmm = 0, mm_best = 0;
@@ -177,7 +251,7 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 				nmm++;
 				if (best - cur > kXdrop)
 					break;
-				int p2 = last_mm_lt<AMB>(D, k);
+				int p2 = M.last_lt(k);
 				int n = k - 1 - p2;
 				if (n > 0) {
 					cur += n;
@@ -198,7 +272,7 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 				nmm++;
 				if (bestr - cur > kXdrop)
 					break;
-				int n2 = first_mm_ge<AMB>(D, k + 1);
+				int n2 = M.first_ge(k + 1);
 				int n = n2 - (k + 1);
 				if (n > 0) {
 					cur += n;
@@ -227,7 +301,7 @@ __device__ void process_candidate(const DbView &db, const uint64_t *rw, const ui
 				h.sstart = (int32_t)sr;
 				h.send = (int32_t)sl;
 			}
-			emit_hit(st, hits, cap, hit_count, h);
+			emit_hit(st, ov, h);
 			covered = br + 1;
 		}
 		pos = e + 1;
@@ -241,29 +315,81 @@ __device__ __forceinline__ void lds_fence()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// counters: [0] hits appended, [1] probes, [2] postings, [3] candidates that passed (1)-(3)
-template <bool AMB>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, ReadsView rd, pgx_hit *hits,
-								      unsigned long long cap,
-								      unsigned long long *counters,
-								      uint32_t *read_cnt)
+// Seed + extend.  Per read (one wavefront):
+//   probes      lanes look the stride-13 16-mers of both strands up in the bucket table
+//   deal        posting counts are prefix-summed over the wave and postings dealt to lanes 64 at a time
+//   filter      with a direct-address index (bits == 32) a posting p of probe q is dropped at once when p-13 is
+//               a posting of probe q-13 (binary search in the neighbour lane's list): the earlier probe
+//               reports that run, and the database is never touched for ~2/3 of the postings
+//   queue       survivors are compacted (ballot + popcount prefix) into an LDS queue and drained 64 at a time,
+//               so the expensive diagonal work always runs with full lanes
+//   output      hits are staged in LDS and leave with ONE atomic per read, contiguously (read_start/read_cnt);
+//               a read that overflows the stage is marked fragmented and goes through the overflow table
+template <bool AMB, bool DENSE>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
+								      uint32_t *__restrict__ read_cnt,
+								      uint32_t *__restrict__ read_start)
 {
-	__shared__ WaveStage s_stage[kWavesPerBlock];
+	__shared__ WaveLds s_lds[kWavesPerBlock];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	WaveStage *st = &s_stage[wave];
+	WaveLds *st = &s_lds[wave];
 	unsigned long long n_probe = 0, n_post = 0, n_runs = 0;
+	const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+	const bool direct_index = !AMB && db.bits >= 32; // the index filter needs exact buckets and no ambiguity codes
 
 	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
 		const int L = (int)rd.len[r];
 		const uint32_t w0 = rd.woff[r];
 		const int nps = L >= kSeedK ? (L - kSeedK) / kProbeStride + 1 : 0;
 		const int P = 2 * nps;
-		unsigned int emitted = 0;
+		unsigned int emitted = 0, q_n = 0;
+		bool frag = false;
 		if (lane == 0) {
 			st->n = 0;
 			st->direct = 0;
 		}
 		lds_fence();
+
+		auto drain = [&](unsigned int cnt) {
+			// the last `cnt` queue entries, one per lane
+			q_n -= cnt;
+			if ((unsigned)lane < cnt) {
+				const uint32_t p = st->qp[q_n + lane], meta = st->qmeta[q_n + lane];
+				const int strand = (int)(meta >> 31), qp = (int)(meta & 0x3FFFFFFFu);
+				const bool tested = (meta >> 30) & 1;
+				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
+				const uint64_t *ra = nullptr;
+				if (AMB) {
+					const uint64_t *a = strand ? rd.rc_amb : rd.fwd_amb;
+					ra = a ? a + w0 : nullptr;
+				}
+				if (DENSE)
+					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, st, ov, n_runs);
+				else
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, st, ov, n_runs);
+			}
+			lds_fence();
+			// a stage more than half full in the middle of a read: the read becomes fragmented
+			unsigned int n = st->n;
+			if (n > (unsigned)kStage / 2) {
+				if (n > (unsigned)kStage)
+					n = kStage;
+				unsigned long long base = 0;
+				if (lane == 0)
+					base = atomicAdd(&ov.counters[4], (unsigned long long)n);
+				base = __shfl(base, 0);
+				for (unsigned int i = lane; i < n; i += 64)
+					if (base + i < ov.ovf_cap)
+						ov.ovf[base + i] = st->hit[i];
+				emitted += n;
+				frag = true;
+				lds_fence();
+				if (lane == 0)
+					st->n = 0;
+				lds_fence();
+			}
+		};
+
 		for (int pbase = 0; pbase < P; pbase += 64) {
 			const int pid = pbase + lane;
 			uint32_t cnt = 0, lo = 0;
@@ -311,54 +437,76 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 				}
 				const uint32_t o_excl = __shfl(excl, o), o_lo = __shfl(lo, o);
 				const int o_strand = __shfl(strand, o), o_qpos = __shfl(qpos, o);
+				// the probe 13 bases to the left on the same strand is the previous lane (if it is in this chunk)
+				const int prev = o > 0 ? o - 1 : 0;
+				const uint32_t v_lo = __shfl(lo, prev), v_cnt = __shfl(cnt, prev);
+				const int v_strand = __shfl(strand, prev), v_qpos = __shfl(qpos, prev);
+				bool keep = active, tested = false;
+				uint32_t p = 0;
 				if (active) {
-					const uint32_t p = db.postings[o_lo + (key - o_excl)];
-					const uint64_t *rw = (o_strand ? rd.rc : rd.fwd) + w0;
-					const uint64_t *ra = nullptr;
-					if (AMB) {
-						const uint64_t *a = o_strand ? rd.rc_amb : rd.fwd_amb;
-						ra = a ? a + w0 : nullptr;
+					const uint32_t raw = db.postings[o_lo + (key - o_excl)];
+					p = raw & 0x7FFFFFFFu;
+					// near_start postings (bit 31): the probe to the left would lie in the previous sequence
+					if (!(raw >> 31) && o_qpos >= kProbeStride && direct_index && o > 0 && v_strand == o_strand &&
+					    v_qpos == o_qpos - kProbeStride) {
+						// is p-13 a posting of the previous probe? (its list is position-sorted)
+						tested = true;
+						if (v_cnt) {
+							const uint32_t want = p - kProbeStride;
+							uint32_t a = 0, b = v_cnt;
+							while (a < b) {
+								uint32_t mid = (a + b) >> 1;
+								if ((db.postings[v_lo + mid] & 0x7FFFFFFFu) < want)
+									a = mid + 1;
+								else
+									b = mid;
+							}
+							if (a < v_cnt && (db.postings[v_lo + a] & 0x7FFFFFFFu) == want)
+								keep = false;
+						}
 					}
-					process_candidate<AMB>(db, rw, ra, L, r, o_strand, o_qpos, p, st, hits, cap, &counters[0], n_runs);
 				}
+				// compact the survivors into the queue
+				const unsigned long long km = __ballot(keep);
+				if (keep) {
+					const unsigned int slot = q_n + (unsigned)__popcll(km & lt_mask);
+					st->qp[slot] = p;
+					st->qmeta[slot] = ((uint32_t)o_strand << 31) | ((uint32_t)tested << 30) | (uint32_t)o_qpos;
+				}
+				q_n += (unsigned)__popcll(km);
 				lds_fence();
-				// flush the stage when it is more than half full (wave-uniform decision)
-				unsigned int n = st->n;
-				if (n > (unsigned)kStage / 2) {
-					if (n > (unsigned)kStage)
-						n = kStage;
-					unsigned long long base = 0;
-					if (lane == 0)
-						base = atomicAdd(&counters[0], (unsigned long long)n);
-					base = __shfl(base, 0);
-					for (unsigned int i = lane; i < n; i += 64)
-						if (base + i < cap)
-							hits[base + i] = st->hit[i];
-					emitted += n;
-					lds_fence();
-					if (lane == 0)
-						st->n = 0;
-					lds_fence();
-				}
+				while (q_n >= 64)
+					drain(64);
 			}
 		}
+		if (q_n)
+			drain(q_n);
 		lds_fence();
 		unsigned int n = st->n;
 		if (n > (unsigned)kStage)
 			n = kStage;
+		if (st->direct)
+			frag = true;
+		uint32_t start = kFragmented;
 		if (n) {
 			unsigned long long base = 0;
 			if (lane == 0)
-				base = atomicAdd(&counters[0], (unsigned long long)n);
+				base = atomicAdd(&ov.counters[frag ? 4 : 0], (unsigned long long)n);
 			base = __shfl(base, 0);
+			pgx_hit *dst = frag ? ov.ovf : ov.main;
+			const unsigned long long dcap = frag ? ov.ovf_cap : ov.main_cap;
 			for (unsigned int i = lane; i < n; i += 64)
-				if (base + i < cap)
-					hits[base + i] = st->hit[i];
+				if (base + i < dcap)
+					dst[base + i] = st->hit[i];
 			emitted += n;
+			if (!frag)
+				start = (uint32_t)base;
 		}
 		emitted += st->direct;
-		if (lane == 0)
+		if (lane == 0) {
 			read_cnt[r] = emitted;
+			read_start[r] = start;
+		}
 		lds_fence();
 	}
 	// per-wave statistics (a handful of atomics per wave, not per read)
@@ -368,9 +516,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 		n_runs += __shfl_down(n_runs, d);
 	}
 	if (lane == 0) {
-		atomicAdd(&counters[1], n_probe);
-		atomicAdd(&counters[2], n_post);
-		atomicAdd(&counters[3], n_runs);
+		atomicAdd(&ov.counters[1], n_probe);
+		atomicAdd(&ov.counters[2], n_post);
+		atomicAdd(&ov.counters[3], n_runs);
 	}
 }
 
@@ -517,6 +665,8 @@ struct SortWave {
 };
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit *__restrict__ hits,
+									 const pgx_hit *__restrict__ scratch,
+									 const uint32_t *__restrict__ read_start,
 									 const uint32_t *__restrict__ off,
 									 uint32_t *__restrict__ read_cnt, uint32_t n_reads,
 									 ConsView cv, int do_consensus,
@@ -541,8 +691,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 				big_list[atomicAdd(big_count, 1u)] = r;
 			continue;
 		}
+		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
+		const uint32_t st0 = read_start[r];
+		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
 		for (uint32_t i = lane; i < n; i += 64)
-			sw->hit[i] = hits[o + i];
+			sw->hit[i] = src[i];
 		lds_fence();
 		// best score of each hit's subject
 		for (uint32_t i = lane; i < n; i += 64) {
@@ -752,11 +905,11 @@ struct EventTimer {
 // Buffers that persist across pipeline calls: the steady state of a batch loop allocates nothing.
 struct Workspace {
 	DevBuf<unsigned long long> counters;
-	DevBuf<pgx_hit> scratch;
-	DevBuf<uint32_t> partial, cursor, big_list, big_count;
+	DevBuf<pgx_hit> scratch, ovf;
+	DevBuf<uint32_t> partial, cursor, big_list, big_count, read_start;
 	DevBuf<pgx_consensus_rec> recs;
 	pgx_hits hits; // used when the caller does not keep the hit table
-	uint64_t hit_cap_hint = 0;
+	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0;
 };
 static Workspace g_ws;
 
@@ -774,7 +927,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_TRY(out->d_read_cnt.ensure(n + 1));
 	PGX_TRY(out->d_read_off.ensure(n + 1));
 	DevBuf<unsigned long long> &counters = g_ws.counters;
-	PGX_TRY(counters.ensure(4));
+	PGX_TRY(counters.ensure(8));
 	if (n == 0) {
 		out->n_hits = 0;
 		return 0;
@@ -786,30 +939,48 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	EventTimer total, t;
 	total.start();
 
-	// seed + extend into a scratch table; grow and repeat if the guess was too small
+	// seed + extend: unfragmented reads land contiguously in `scratch`, the rest in `ovf`;
+	// grow and repeat if a guess was too small
 	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(n * 40, 1 << 16), g_ws.hit_cap_hint);
-	DevBuf<pgx_hit> &scratch = g_ws.scratch;
-	unsigned long long h_cnt[4];
+	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(n / 4, 1 << 16), g_ws.ovf_cap_hint);
+	DevBuf<pgx_hit> &scratch = g_ws.scratch, &ovf = g_ws.ovf;
+	DevBuf<uint32_t> &read_start = g_ws.read_start;
+	PGX_TRY(read_start.ensure(n));
+	unsigned long long h_cnt[8];
+	const bool dense = rd->max_len <= 192;
 	for (;;) {
 		PGX_TRY(scratch.ensure(cap));
+		PGX_TRY(ovf.ensure(ovf_cap));
 		cap = scratch.n;
-		PGX_HIP(hipMemsetAsync(counters.data(), 0, 4 * sizeof(unsigned long long), 0));
+		ovf_cap = ovf.n;
+		PGX_HIP(hipMemsetAsync(counters.data(), 0, 8 * sizeof(unsigned long long), 0));
+		OutView ov;
+		ov.main = scratch.data();
+		ov.ovf = ovf.data();
+		ov.main_cap = cap;
+		ov.ovf_cap = ovf_cap;
+		ov.counters = counters.data();
 		t.start();
-		if (amb)
-			hipLaunchKernelGGL(k_seed_extend<true>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, dv, rv,
-					   scratch.data(), (unsigned long long)cap, counters.data(), out->d_read_cnt.data());
+		const dim3 g(grid), b(64 * kWavesPerBlock);
+		if (amb && dense)
+			hipLaunchKernelGGL((k_seed_extend<true, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+		else if (amb)
+			hipLaunchKernelGGL((k_seed_extend<true, false>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+		else if (dense)
+			hipLaunchKernelGGL((k_seed_extend<false, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
 		else
-			hipLaunchKernelGGL(k_seed_extend<false>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, dv, rv,
-					   scratch.data(), (unsigned long long)cap, counters.data(), out->d_read_cnt.data());
+			hipLaunchKernelGGL((k_seed_extend<false, false>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
 		PGX_HIP(hipGetLastError());
 		g_times.seed_extend_ms = t.stop();
-		PGX_TRY(counters.download(h_cnt, 4));
-		if (h_cnt[0] <= cap)
+		PGX_TRY(counters.download(h_cnt, 8));
+		if (h_cnt[0] <= cap && h_cnt[4] <= ovf_cap)
 			break;
-		cap = h_cnt[0] + h_cnt[0] / 8;
+		cap = std::max<uint64_t>(cap, h_cnt[0] + h_cnt[0] / 8);
+		ovf_cap = std::max<uint64_t>(ovf_cap, h_cnt[4] + h_cnt[4] / 8);
 	}
-	const uint64_t H = h_cnt[0];
-	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, H + H / 16);
+	const uint64_t H_main = h_cnt[0], H_ovf = h_cnt[4], H = H_main + H_ovf;
+	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, H_main + H_main / 16);
+	g_ws.ovf_cap_hint = std::max<uint64_t>(g_ws.ovf_cap_hint, H_ovf + H_ovf / 16);
 	out->n_hits = (int64_t)H;
 	g_times.hits = (int64_t)H;
 	g_times.probes = (int64_t)h_cnt[1];
@@ -819,22 +990,22 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
 			    (unsigned long long)H);
 
-	// group by read: exclusive scan of the per-read counts, then scatter
+	// group by read: exclusive scan of the per-read counts; only the overflow hits need a scatter
 	t.start();
 	const uint32_t n_part = (uint32_t)((n + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
 	DevBuf<uint32_t> &partial = g_ws.partial, &cursor = g_ws.cursor;
 	PGX_TRY(partial.ensure(n_part));
-	PGX_TRY(cursor.ensure(n));
-	PGX_HIP(hipMemsetAsync(cursor.data(), 0, n * sizeof(uint32_t), 0));
 	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data());
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, 0, partial.data(), n_part);
 	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data(),
 			   out->d_read_off.data());
 	PGX_HIP(hipGetLastError());
 	PGX_TRY(out->d_hits.ensure(H ? H : 1));
-	if (H) {
-		const int g2 = (int)std::min<uint64_t>((H + 255) / 256, 256ull * 16);
-		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, scratch.data(), H, out->d_read_off.data(),
+	if (H_ovf) {
+		PGX_TRY(cursor.ensure(n));
+		PGX_HIP(hipMemsetAsync(cursor.data(), 0, n * sizeof(uint32_t), 0));
+		const int g2 = (int)std::min<uint64_t>((H_ovf + 255) / 256, 256ull * 16);
+		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, ovf.data(), H_ovf, out->d_read_off.data(),
 				   cursor.data(), out->d_hits.data());
 		PGX_HIP(hipGetLastError());
 	}
@@ -848,8 +1019,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_HIP(hipMemsetAsync(big_count.data(), 0, sizeof(uint32_t), 0));
 	const ConsView cv = cons_view(db, rdp);
 	const size_t lds = sizeof(SortWave) * kWavesPerBlock;
-	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), lds, 0, out->d_hits.data(),
-			   out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, d_recs,
+	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), lds, 0, out->d_hits.data(), scratch.data(),
+			   read_start.data(), out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, d_recs,
 			   big_list.data(), big_count.data());
 	PGX_HIP(hipGetLastError());
 	uint32_t n_big = 0;

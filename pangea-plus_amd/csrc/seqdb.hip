@@ -93,6 +93,13 @@ static std::string first_word(const std::string &h)
 
 int choose_index_bits(int64_t n_postings)
 {
+	// PGX_INDEX_BITS forces the bucket-table width (tests use 32 to exercise the direct-address paths on
+	// small databases)
+	if (const char *e = getenv("PGX_INDEX_BITS")) {
+		int v = atoi(e);
+		if (v >= 16 && v <= 32)
+			return v;
+	}
 	int lg = 0;
 	while (lg < 62 && (1ll << lg) < n_postings)
 		lg++;
@@ -123,14 +130,21 @@ __global__ void k_blk_subj(const uint32_t *__restrict__ seq_off, uint32_t n_seq,
 	blk[b] = lo;
 }
 
-__global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, int bits, uint32_t *__restrict__ keys,
-			    uint32_t *__restrict__ vals)
+// posting = position | near_start << 31, where near_start marks the first 13 positions of every sequence:
+// there the probe 13 bases to the left lies (partly) in the previous sequence, so the index-side duplicate
+// filter of k_seed_extend must not trust it
+__global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, int bits, const uint32_t *__restrict__ seq_off,
+			    const uint32_t *__restrict__ blk_subj, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n_pos; i += stride) {
 		keys[i] = seed_bucket(kmer16(words, (int64_t)i), bits);
-		vals[i] = (uint32_t)i;
+		uint32_t s = blk_subj[i >> 6];
+		while (seq_off[s + 1] <= i)
+			s++;
+		const uint32_t near_start = (uint32_t)(i - seq_off[s]) < (uint32_t)kProbeStride;
+		vals[i] = (uint32_t)i | (near_start << 31);
 	}
 }
 
@@ -180,7 +194,7 @@ int db_build_index(pgx_db *db)
 	PGX_TRY(vals_in.alloc(n));
 	int grid = (int)std::min<uint64_t>((n + 255) / 256, 256 * 32);
 	hipLaunchKernelGGL(k_seed_keys, dim3(grid), dim3(256), 0, 0, db->d_words.data(), n, db->index_bits,
-			   keys_in.data(), vals_in.data());
+			   db->d_seq_off.data(), db->d_blk_subj.data(), keys_in.data(), vals_in.data());
 	PGX_HIP(hipGetLastError());
 	size_t tmp_bytes = 0;
 	PGX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.data(), keys_out.data(), vals_in.data(),
@@ -222,8 +236,8 @@ static int db_upload_offsets(pgx_db *db)
 int db_upload_and_index(pgx_db *db)
 {
 	PGX_TRY(require_device());
-	if (db->n_bases >= (1ll << 32) - 64)
-		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 32-bit position limit of this build",
+	if (db->n_bases >= (1ll << 31) - 64)
+		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 31-bit position limit of this build",
 			    (long long)db->n_bases);
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
 	PGX_TRY(db->d_words.alloc(nw, 1, 2, true));
@@ -654,9 +668,9 @@ int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out)
 	pgx_db *db = new pgx_db();
 	db->n_seq = cfg->n_seq;
 	db->n_bases = cfg->n_seq * (int64_t)cfg->seq_len;
-	if (db->n_bases >= (1ll << 32) - 64) {
+	if (db->n_bases >= (1ll << 31) - 64) {
 		delete db;
-		return fail(PGX_E_LIMIT, "synthetic database exceeds the 32-bit position limit");
+		return fail(PGX_E_LIMIT, "synthetic database exceeds the 31-bit position limit");
 	}
 	db->h_seq_off.resize((size_t)db->n_seq + 1);
 	for (int64_t i = 0; i <= db->n_seq; i++)

@@ -72,3 +72,85 @@ def test_blast_fasta_path_matches_oracle_bytes(pg, workload, tmp_path):
         pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(p), rank=rk, world_size=3)
         parts += p.read_bytes()
     assert parts == out.read_bytes()
+
+
+def _blast_text(pg, db_fa, reads_fa, tmp_path, tag):
+    out = tmp_path / (tag + ".tsv")
+    pg.makeblastdb(str(db_fa), str(tmp_path / (tag + "_db")))
+    pg.blastn(str(reads_fa), str(tmp_path / (tag + "_db")), str(out))
+    return out.read_bytes()
+
+
+def test_direct_address_index_paths_match_oracle(pg, workload, oracle_bin, tmp_path, monkeypatch):
+    """bits = 32 turns on the index-side duplicate filter (and its proxy for seeds that straddle two
+    subjects); it is chosen automatically only above 0.5 Gbp, so force it here."""
+    monkeypatch.setenv("PGX_INDEX_BITS", "32")
+    assert _blast_text(pg, workload / "db.fa", workload / "reads.fa", tmp_path, "b32") == \
+        open(workload / "oracle.tsv", "rb").read()
+    # adjacent database sequences that continue each other: seeds straddle the boundaries
+    import random
+    rng = random.Random(9)
+    g = "".join(rng.choice("ACGT") for _ in range(3000))
+    cuts = [0, 200, 413, 655, 1000, 1013, 1500, 2100, 3000]
+    db = tmp_path / "adj.fa"
+    db.write_text("".join(">gi|%d|x|p%d|\n%s\n" % (i + 1, i, g[a:b]) for i, (a, b) in enumerate(zip(cuts, cuts[1:]))))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for i in range(400):
+        o = rng.randrange(0, 3000 - 150)
+        w = list(g[o:o + 150])
+        for p_ in rng.sample(range(150), rng.choice([0, 0, 1, 2, 4])):
+            w[p_] = rng.choice([b for b in "ACGT" if b != w[p_]])
+        w = "".join(w)
+        if i % 2:
+            w = "".join(comp[c] for c in reversed(w))
+        reads.append(">a%d\n%s\n" % (i, w))
+    rd = tmp_path / "adj_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "adj_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)])[0] == 0
+    assert len(want.read_bytes()) > 20000
+    assert _blast_text(pg, db, rd, tmp_path, "adj32") == want.read_bytes()
+    monkeypatch.delenv("PGX_INDEX_BITS")
+    assert _blast_text(pg, db, rd, tmp_path, "adjauto") == want.read_bytes()
+
+
+def test_long_queries_ambiguity_codes_and_heavy_reads(pg, oracle_bin, tmp_path, monkeypatch):
+    """1 400-bp queries (config 2 shape: lazy masks, >64 probes per strand), IUPAC codes on both sides, and a
+    repeated database in which every read collects hundreds of hits (fragmented output, big-read ordering,
+    500-subject limit)."""
+    import random
+    rng = random.Random(21)
+    base = "".join(rng.choice("ACGT") for _ in range(1600))
+    seqs = []
+    for i in range(700):
+        s = list(base)
+        for p_ in rng.sample(range(1600), 16):
+            s[p_] = rng.choice("ACGT")
+        if i % 7 == 0:
+            for p_ in rng.sample(range(1600), 5):
+                s[p_] = rng.choice("NRYKM")
+        seqs.append("".join(s))
+    db = tmp_path / "rep.fa"
+    db.write_text("".join(">gi|%d|x|r%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    reads = []
+    for i in range(60):
+        L = rng.choice([150, 150, 400, 1400])
+        o = rng.randrange(0, 1600 - L)
+        w = list(rng.choice(seqs)[o:o + L])
+        for p_ in rng.sample(range(L), max(1, L // 60)):
+            w[p_] = rng.choice("ACGTN")
+        reads.append(">h%d\n%s\n" % (i, "".join(w)))
+    rd = tmp_path / "rep_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "rep_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want),
+                    "-num_threads", "8"], timeout=900)[0] == 0
+    lines = want.read_text().splitlines()
+    per_read = {}
+    for l in lines:
+        per_read.setdefault(l.split("\t")[0], set()).add(l.split("\t")[1])
+    assert max(len(v) for v in per_read.values()) == 500      # the 500-subject limit is exercised
+    assert _blast_text(pg, db, rd, tmp_path, "rep") == want.read_bytes()
+    monkeypatch.setenv("PGX_INDEX_BITS", "32")
+    assert _blast_text(pg, db, rd, tmp_path, "rep32") == want.read_bytes()
