@@ -242,7 +242,8 @@ __global__ void k_consensus_groups(const uint32_t *__restrict__ g_first, const u
 // rank index that equal nothing
 __global__ void k_synth_rdp(uint64_t read_seed, uint64_t n_seq, uint32_t seq_len, uint32_t read_len, uint64_t first,
 			    uint64_t count, const int64_t *__restrict__ level_cnt, const int64_t *__restrict__ level_base,
-			    const uint32_t *__restrict__ node_name_tok, uint32_t *__restrict__ name, int8_t *__restrict__ rank)
+			    const uint32_t *__restrict__ node_name_tok, uint32_t *__restrict__ name, int8_t *__restrict__ rank,
+			    uint32_t *__restrict__ code)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= count)
@@ -260,8 +261,10 @@ __global__ void k_synth_rdp(uint64_t read_seed, uint64_t n_seq, uint32_t seq_len
 	for (int k = 0; k < 6; k++) {
 		const bool keep = synth_hash(read_seed, 5, r, (uint64_t)k) % 10 != 0;
 		const int64_t taxid = level_base[k] + anc[k];
-		name[i * 6 + k] = keep ? node_name_tok[taxid] : 0xFFFFFFFFu;
+		const uint32_t nm = keep ? node_name_tok[taxid] : 0xFFFFFFFFu;
+		name[i * 6 + k] = nm;
 		rank[i * 6 + k] = keep ? (int8_t)k : (int8_t)-2;
+		code[i * 6 + k] = keep ? ((nm << 3) | (uint32_t)(k + 1)) : 0xFFFFFFFFu;
 	}
 }
 
@@ -417,6 +420,25 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	PGX_TRY(db->d_subj_tok.upload(toks.data(), toks.size()));
 	PGX_TRY(db->d_tok_rank.alloc(db->h_tok_rank.size()));
 	PGX_TRY(db->d_tok_rank.upload(db->h_tok_rank.data(), db->h_tok_rank.size()));
+	{
+		std::vector<uint32_t> pairs(n * 16, 0);
+		for (size_t i = 0; i < n; i++) {
+			const uint32_t t0 = off[i], nt = off[i + 1] - t0, np = (nt + 1) / 2;
+			uint32_t *rec = &pairs[i * 16];
+			if (np > 15 || nt > 0xFFFF) {
+				rec[0] = (nt & 0xFFFF) | (0xFFFFu << 16);
+				continue;
+			}
+			rec[0] = nt | (np << 16);
+			for (uint32_t a = 0; a < np; a++) {
+				const uint32_t rk = (uint32_t)(db->h_tok_rank[toks[t0 + 2 * a]] + 1);
+				const uint32_t nm = 2 * a + 1 < nt ? toks[t0 + 2 * a + 1] : 0u;
+				rec[1 + a] = (nm << 3) | rk;
+			}
+		}
+		PGX_TRY(db->d_subj_pairs.alloc(pairs.size() ? pairs.size() : 16));
+		PGX_TRY(db->d_subj_pairs.upload(pairs.data(), pairs.size()));
+	}
 	// similarity order of every "%.2f" text from 0.00 to 100.00, plus "" and "0"
 	std::vector<std::string> sims;
 	char buf[16];
@@ -516,10 +538,12 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		for (size_t b = 0; b < f.size(); b += 3)
 			per[r].emplace_back(db->intern(clean_rdp_name(f[b])), b + 1 < f.size() ? rdp_rank_index(f[b + 1]) : (int8_t)-1);
 	}
+	std::vector<uint32_t> code;
 	for (size_t r = 0; r < n; r++) {
 		for (auto &p : per[r]) {
 			name.push_back(p.first);
 			rank.push_back(p.second);
+			code.push_back((p.first << 3) | (uint32_t)(p.second + 1));
 		}
 		off[r + 1] = (uint32_t)name.size();
 	}
@@ -531,6 +555,8 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	if (rc == 0) rc = rd->d_name.upload(name.data(), name.size());
 	if (rc == 0) rc = rd->d_rank.alloc(rank.size() ? rank.size() : 1);
 	if (rc == 0) rc = rd->d_rank.upload(rank.data(), rank.size());
+	if (rc == 0) rc = rd->d_code.alloc(code.size() ? code.size() : 1);
+	if (rc == 0) rc = rd->d_code.upload(code.data(), code.size());
 	if (rc == 0) rc = rd->d_present.alloc(present.size());
 	if (rc == 0) rc = rd->d_present.upload(present.data(), present.size());
 	if (rc < 0) {
@@ -583,6 +609,7 @@ int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, c
 	if (rc == 0) rc = rd->d_off.upload(off.data(), off.size());
 	if (rc == 0) rc = rd->d_name.alloc((size_t)count * 6 + 1);
 	if (rc == 0) rc = rd->d_rank.alloc((size_t)count * 6 + 1);
+	if (rc == 0) rc = rd->d_code.alloc((size_t)count * 6 + 1);
 	if (rc == 0) rc = rd->d_present.alloc((size_t)count + 1);
 	if (rc == 0 && hipMemset(rd->d_present.data(), 1, (size_t)count + 1) != hipSuccess)
 		rc = fail(PGX_E_NODEVICE, "hipMemset failed");
@@ -590,7 +617,7 @@ int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, c
 		hipLaunchKernelGGL(k_synth_rdp, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, cfg->read_seed,
 				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint32_t)cfg->read_len, (uint64_t)first,
 				   (uint64_t)count, d_cnt.data(), d_base.data(), db->d_node_name_tok.data(), rd->d_name.data(),
-				   rd->d_rank.data());
+				   rd->d_rank.data(), rd->d_code.data());
 		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
 			rc = fail(PGX_E_NODEVICE, "k_synth_rdp failed");
 	}

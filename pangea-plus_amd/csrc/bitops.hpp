@@ -15,6 +15,7 @@ constexpr int kSeedK = 16;                    // probe k-mer: 16 bases = one 32-
 constexpr int kWord = 28;                     // megablast word size W (spec S3)
 constexpr int kProbeStride = kWord - kSeedK + 1; // 13: every exact 28-mer holds one probe
 constexpr int kXdrop = 10;
+constexpr int kBlkShift = 9;                   // blk_subj[b] = subject holding base b << 9 (512-base blocks)
 
 // 64 bits (32 bases) of a packed stream starting at base position `pos` (pos >= -32)
 __device__ __forceinline__ uint64_t window64(const uint64_t *words, int64_t pos)

@@ -30,6 +30,7 @@ struct DbView {
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
 	uint32_t n_seq;
 	int bits;
+	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
 };
 
 struct ReadsView {
@@ -162,13 +163,15 @@ template <bool AMB> struct LazyMask {
 };
 
 constexpr int kStage = 128; // hits staged in LDS per wave between flushes
-constexpr int kQueue = 128; // candidate queue per wave (filled 64 at a time, drained at >= 64)
+constexpr int kDeal = 2;     // postings dealt per lane per round (independent loads in flight)
+constexpr int kQueue = 64 * (kDeal + 1); // candidate queue per wave (filled 64*kDeal at a time, drained at >= 64)
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
 struct WaveLds {
 	pgx_hit hit[kStage];
-	uint32_t qp[kQueue], qmeta[kQueue]; // queued candidates: posting, strand << 31 | tested << 30 | qpos
+	// queued candidates: posting, strand << 31 | tested << 30 | qpos, and the subject found while filtering
+	uint32_t qp[kQueue], qmeta[kQueue], qsubj[kQueue], qs0[kQueue], qs1[kQueue];
 	unsigned int n;                      // staged hits
 	unsigned int direct;                 // hits that found the stage full and went straight to the overflow table
 };
@@ -196,13 +199,9 @@ __device__ __forceinline__ void emit_hit(WaveLds *st, const OutView &ov, const p
 // this probe is the left-most one of its exact run (test 1 below).
 template <bool AMB, class Mask>
 __device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read,
-						   int strand, int qp, uint32_t p, bool tested, WaveLds *st, const OutView &ov,
-						   unsigned long long &n_runs)
+						   int strand, int qp, uint32_t p, bool tested, uint32_t s, uint32_t s_start,
+						   uint32_t s_end, WaveLds *st, const OutView &ov, unsigned long long &n_runs)
 {
-	uint32_t s = db.blk_subj[p >> 6];
-	while (db.seq_off[s + 1] <= p)
-		s++;
-	const uint32_t s_start = db.seq_off[s], s_end = db.seq_off[s + 1];
 	if (p + (uint32_t)kSeedK > s_end)
 		return; // seed straddles two subjects
 	Diag D;
@@ -335,7 +334,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	WaveLds *st = &s_lds[wave];
 	unsigned long long n_probe = 0, n_post = 0, n_runs = 0;
 	const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-	const bool direct_index = !AMB && db.bits >= 32; // the index filter needs exact buckets and no ambiguity codes
 
 	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
 		const int L = (int)rd.len[r];
@@ -353,8 +351,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 		auto drain = [&](unsigned int cnt) {
 			// the last `cnt` queue entries, one per lane
 			q_n -= cnt;
-			if ((unsigned)lane < cnt) {
+			if ((unsigned)lane < cnt && db.dbg_stop != 3) {
 				const uint32_t p = st->qp[q_n + lane], meta = st->qmeta[q_n + lane];
+				const uint32_t sj = st->qsubj[q_n + lane], s0 = st->qs0[q_n + lane], s1 = st->qs1[q_n + lane];
 				const int strand = (int)(meta >> 31), qp = (int)(meta & 0x3FFFFFFFu);
 				const bool tested = (meta >> 30) & 1;
 				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
@@ -364,9 +363,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 					ra = a ? a + w0 : nullptr;
 				}
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, st, ov, n_runs);
+					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, sj, s0, s1, st, ov, n_runs);
 				else
-					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, st, ov, n_runs);
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, sj, s0, s1, st, ov, n_runs);
 			}
 			lds_fence();
 			// a stage more than half full in the middle of a read: the read becomes fragmented
@@ -422,58 +421,90 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 			const uint32_t T = __shfl(incl, 63);
 			n_probe += (pid < P);
 			n_post += cnt;
-			for (uint32_t it = 0; it < T; it += 64) {
-				const uint32_t item = it + lane;
-				const bool active = item < T;
-				const uint32_t key = active ? item : T - 1;
-				// owner probe: the last lane whose exclusive prefix is <= item
-				int o = 0;
+			if (db.dbg_stop == 1)
+				continue;
+			for (uint32_t it = 0; it < T; it += 64 * kDeal) {
+				// kDeal postings per lane, every load of a stage issued before the first use
+				bool active[kDeal], tested[kDeal], keep[kDeal];
+				uint32_t pidx[kDeal], p[kDeal], sj[kDeal], s0[kDeal], s1[kDeal];
+				int o_strand[kDeal], o_qpos[kDeal];
 #pragma unroll
-				for (int step = 32; step >= 1; step >>= 1) {
-					int cand = o + step;
-					uint32_t e = __shfl(excl, cand & 63);
-					if (cand < 64 && e <= key)
-						o = cand;
+				for (int u = 0; u < kDeal; u++) {
+					const uint32_t item = it + 64 * u + lane;
+					active[u] = item < T;
+					const uint32_t key = active[u] ? item : T - 1;
+					// owner probe: the last lane whose exclusive prefix is <= item
+					int o = 0;
+#pragma unroll
+					for (int step = 32; step >= 1; step >>= 1) {
+						int cand = o + step;
+						uint32_t e = __shfl(excl, cand & 63);
+						if (cand < 64 && e <= key)
+							o = cand;
+					}
+					pidx[u] = __shfl(lo, o) + (key - __shfl(excl, o));
+					o_strand[u] = __shfl(strand, o);
+					o_qpos[u] = __shfl(qpos, o);
 				}
-				const uint32_t o_excl = __shfl(excl, o), o_lo = __shfl(lo, o);
-				const int o_strand = __shfl(strand, o), o_qpos = __shfl(qpos, o);
-				// the probe 13 bases to the left on the same strand is the previous lane (if it is in this chunk)
-				const int prev = o > 0 ? o - 1 : 0;
-				const uint32_t v_lo = __shfl(lo, prev), v_cnt = __shfl(cnt, prev);
-				const int v_strand = __shfl(strand, prev), v_qpos = __shfl(qpos, prev);
-				bool keep = active, tested = false;
-				uint32_t p = 0;
-				if (active) {
-					const uint32_t raw = db.postings[o_lo + (key - o_excl)];
-					p = raw & 0x7FFFFFFFu;
-					// near_start postings (bit 31): the probe to the left would lie in the previous sequence
-					if (!(raw >> 31) && o_qpos >= kProbeStride && direct_index && o > 0 && v_strand == o_strand &&
-					    v_qpos == o_qpos - kProbeStride) {
-						// is p-13 a posting of the previous probe? (its list is position-sorted)
-						tested = true;
-						if (v_cnt) {
-							const uint32_t want = p - kProbeStride;
-							uint32_t a = 0, b = v_cnt;
-							while (a < b) {
-								uint32_t mid = (a + b) >> 1;
-								if ((db.postings[v_lo + mid] & 0x7FFFFFFFu) < want)
-									a = mid + 1;
-								else
-									b = mid;
-							}
-							if (a < v_cnt && (db.postings[v_lo + a] & 0x7FFFFFFFu) == want)
-								keep = false;
+				uint32_t raw[kDeal];
+#pragma unroll
+				for (int u = 0; u < kDeal; u++)
+					raw[u] = active[u] ? db.postings[pidx[u]] : 0u;
+				// stage 2: block table entry of the posting and, unless the posting sits within 13 bases of a
+				// sequence start (bit 31), the database 16-mer 13 bases to its left
+				uint32_t left[kDeal], want[kDeal];
+#pragma unroll
+				for (int u = 0; u < kDeal; u++) {
+					p[u] = raw[u] & 0x7FFFFFFFu;
+					keep[u] = active[u];
+					tested[u] = false;
+					left[u] = want[u] = 0;
+					sj[u] = 0;
+					if (active[u]) {
+						sj[u] = db.blk_subj[p[u] >> kBlkShift];
+						if (!AMB && !(raw[u] >> 31) && o_qpos[u] >= kProbeStride) {
+							tested[u] = true;
+							left[u] = kmer16(db.words, (int64_t)p[u] - kProbeStride);
+							want[u] = kmer16((o_strand[u] ? rd.rc : rd.fwd) + w0, o_qpos[u] - kProbeStride);
 						}
 					}
 				}
-				// compact the survivors into the queue
-				const unsigned long long km = __ballot(keep);
-				if (keep) {
-					const unsigned int slot = q_n + (unsigned)__popcll(km & lt_mask);
-					st->qp[slot] = p;
-					st->qmeta[slot] = ((uint32_t)o_strand << 31) | ((uint32_t)tested << 30) | (uint32_t)o_qpos;
+				// stage 3: an equal 16-mer to the left means the previous probe reports this run: drop
+#pragma unroll
+				for (int u = 0; u < kDeal; u++) {
+					if (tested[u] && left[u] == want[u])
+						keep[u] = false;
+					s0[u] = s1[u] = 0;
+					if (keep[u]) {
+						uint32_t a = db.seq_off[sj[u]], b = db.seq_off[sj[u] + 1];
+						while (b <= p[u]) {
+							sj[u]++;
+							a = b;
+							b = db.seq_off[sj[u] + 1];
+						}
+						s0[u] = a;
+						s1[u] = b;
+					}
 				}
-				q_n += (unsigned)__popcll(km);
+				if (db.dbg_stop == 2) {
+					for (int u = 0; u < kDeal; u++)
+						n_runs += keep[u] + s1[u];
+					continue;
+				}
+				// compact the survivors into the queue
+#pragma unroll
+				for (int u = 0; u < kDeal; u++) {
+					const unsigned long long km = __ballot(keep[u]);
+					if (keep[u]) {
+						const unsigned int slot = q_n + (unsigned)__popcll(km & lt_mask);
+						st->qp[slot] = p[u];
+						st->qmeta[slot] = ((uint32_t)o_strand[u] << 31) | ((uint32_t)tested[u] << 30) | (uint32_t)o_qpos[u];
+						st->qsubj[slot] = sj[u];
+						st->qs0[slot] = s0[u];
+						st->qs1[slot] = s1[u];
+					}
+					q_n += (unsigned)__popcll(km);
+				}
 				lds_fence();
 				while (q_n >= 64)
 					drain(64);
@@ -645,7 +676,39 @@ struct ConsView {
 	const uint32_t *rdp_off, *rdp_name;
 	const int8_t *rdp_rank;
 	const uint8_t *rdp_present;
+	const uint32_t *subj_pairs; // 16 words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
+	const uint32_t *rdp_code;   // name << 3 | rank + 1 per RDP triplet
 };
+
+constexpr int kRdpRegs = 8; // RDP triplets of a read kept in registers by the fast agreement count
+
+// fast (rank,name) agreement: one 64-byte record per subject against the read's RDP codes in registers
+__device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t subject, const uint32_t (&rc)[kRdpRegs],
+						  uint32_t r0, uint32_t r1, uint32_t *ntok_out)
+{
+	const uint4 *rec = reinterpret_cast<const uint4 *>(cv.subj_pairs + 16ull * subject);
+	const uint4 q0 = rec[0];
+	const uint32_t nt = q0.x & 0xFFFFu, np = q0.x >> 16;
+	*ntok_out = nt;
+	if (np == 0xFFFFu || r1 - r0 > (uint32_t)kRdpRegs) {
+		// more pairs / triplets than the record or the registers hold: the general count
+		const uint32_t t0 = cv.subj_tok_off[subject], n2 = cv.subj_tok_off[subject + 1] - t0;
+		*ntok_out = n2;
+		return rank_matches(cv.subj_tok + t0, n2, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
+	}
+	const uint4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
+	const uint32_t pr[15] = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+	uint32_t rm = 0;
+#pragma unroll
+	for (int a = 0; a < 15; a++) {
+		if ((uint32_t)a < np) {
+#pragma unroll
+			for (int b = 0; b < kRdpRegs; b++)
+				rm += pr[a] == rc[b];
+		}
+	}
+	return rm;
+}
 
 // (rank,name) agreement of one hit with the read's RDP triplets
 __device__ __forceinline__ uint32_t hit_rank_matches(const ConsView &cv, uint32_t subject, uint32_t r0, uint32_t r1,
@@ -696,6 +759,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
 		for (uint32_t i = lane; i < n; i += 64)
 			sw->hit[i] = src[i];
+		// the read's RDP codes, wave-uniform, in registers (slots past the end match nothing)
+		uint32_t rcode[kRdpRegs], rdp0 = 0, rdp1 = 0;
+		if (do_consensus) {
+			rdp0 = __builtin_amdgcn_readfirstlane(cv.rdp_off[r]);
+			rdp1 = __builtin_amdgcn_readfirstlane(cv.rdp_off[r + 1]);
+#pragma unroll
+			for (int b = 0; b < kRdpRegs; b++)
+				rcode[b] = rdp0 + b < rdp1 ? cv.rdp_code[rdp0 + b] : 0xFFFFFFFEu;
+		}
 		lds_fence();
 		// best score of each hit's subject
 		for (uint32_t i = lane; i < n; i += 64) {
@@ -718,8 +790,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 			hits[o + rank] = h;
 			if (do_consensus) {
 				uint32_t ntok;
-				const uint32_t r0 = cv.rdp_off[r], r1 = cv.rdp_off[r + 1];
-				sw->rm[rank] = hit_rank_matches(cv, (uint32_t)h.subject, r0, r1, &ntok);
+				sw->rm[rank] = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
 				sw->ntok[rank] = ntok;
 				const int len = h.qend - h.qstart + 1;
 				sw->sim[rank] = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
@@ -842,6 +913,7 @@ static DbView db_view(const pgx_db *db)
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;
 	v.bits = db->index_bits;
+	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0;
 	return v;
 }
 
@@ -866,6 +938,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 		cv.subj_tok_off = db->d_subj_tok_off.data();
 		cv.subj_tok = db->d_subj_tok.data();
 		cv.tok_rank = db->d_tok_rank.data();
+		cv.subj_pairs = db->d_subj_pairs.data();
 		cv.simrank_lut = db->d_simrank_lut.data();
 		cv.simrank_undef = db->simrank_undef;
 		cv.simrank_zero = db->simrank_zero;
@@ -875,6 +948,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 		cv.rdp_name = rdp->d_name.data();
 		cv.rdp_rank = rdp->d_rank.data();
 		cv.rdp_present = rdp->d_present.data();
+		cv.rdp_code = rdp->d_code.data();
 	}
 	return cv;
 }

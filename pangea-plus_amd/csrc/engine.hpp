@@ -10,7 +10,7 @@
 // Sequence database in HBM.
 //   d_words     2-bit packed bases of all sequences back to back (1 zero word in front, 2 behind)
 //   d_amb       optional spaced ambiguity flags, same geometry (absent when the DB is pure ACGT)
-//   d_seq_off   n_seq+1 base offsets;  d_blk_subj[b] = subject holding base 64*b
+//   d_seq_off   n_seq+1 base offsets;  d_blk_subj[b] = subject holding base 512*b
 //   seed index  every 16-mer start position of the concatenation, grouped by
 //               seed_bucket(kmer, index_bits):  d_bucket_off[2^bits + 1], d_postings[n_postings]
 //               (ascending position inside a bucket).  At 1 Gbp: bits = 32 (17.2 GB of offsets +
@@ -38,6 +38,9 @@ struct pgx_db {
 	std::unordered_map<std::string, uint32_t> token_id;
 	pgx::DevBuf<uint32_t> d_subj_tok_off, d_subj_tok; // CSR of token ids per subject
 	pgx::DevBuf<int8_t> d_tok_rank;                   // token id -> index in "0".."6" or -1
+	// 64-byte record per subject for the consensus kernel: [0] = ntok | npairs << 16 (npairs 0xFFFF: use the
+	// CSR), [1..15] = (name id << 3 | rank index + 1) of each (rank,name) pair
+	pgx::DevBuf<uint32_t> d_subj_pairs;
 	std::vector<int8_t> h_tok_rank;
 	std::vector<int32_t> subj_taxid;
 	pgx::DevBuf<uint32_t> d_node_name_tok;       // taxid -> token id of a one-word scientific name (else 0)
@@ -75,6 +78,7 @@ struct pgx_rdp {
 	pgx::DevBuf<uint32_t> d_off;   // n+1, in triplets
 	pgx::DevBuf<uint32_t> d_name;  // token id of the cleaned name
 	pgx::DevBuf<int8_t> d_rank;    // index in (domain..species) or -1
+	pgx::DevBuf<uint32_t> d_code;  // name << 3 | rank + 1 (0xFFFFFFFF: matches nothing)
 	pgx::DevBuf<uint8_t> d_present; // 0: read has no RDP line (never selected)
 };
 

@@ -118,7 +118,7 @@ __global__ void k_blk_subj(const uint32_t *__restrict__ seq_off, uint32_t n_seq,
 	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blk)
 		return;
-	uint64_t p = b * 64;
+	uint64_t p = b << kBlkShift;
 	uint32_t lo = 0, hi = n_seq; // last subject with seq_off <= p
 	while (hi - lo > 1) {
 		uint32_t mid = lo + (hi - lo) / 2;
@@ -140,7 +140,7 @@ __global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, 
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n_pos; i += stride) {
 		keys[i] = seed_bucket(kmer16(words, (int64_t)i), bits);
-		uint32_t s = blk_subj[i >> 6];
+		uint32_t s = blk_subj[i >> kBlkShift];
 		while (seq_off[s + 1] <= i)
 			s++;
 		const uint32_t near_start = (uint32_t)(i - seq_off[s]) < (uint32_t)kProbeStride;
@@ -223,7 +223,7 @@ static int db_upload_offsets(pgx_db *db)
 {
 	PGX_TRY(db->d_seq_off.alloc((size_t)db->n_seq + 1));
 	PGX_TRY(db->d_seq_off.upload(db->h_seq_off.data(), (size_t)db->n_seq + 1));
-	uint64_t n_blk = ((uint64_t)db->n_bases + 63) / 64 + 1;
+	uint64_t n_blk = ((uint64_t)db->n_bases >> kBlkShift) + 2;
 	PGX_TRY(db->d_blk_subj.alloc(n_blk));
 	if (db->n_seq > 0) {
 		hipLaunchKernelGGL(k_blk_subj, dim3((unsigned)((n_blk + 255) / 256)), dim3(256), 0, 0,
@@ -816,7 +816,7 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 	if (rc == 0)
 		rc = db->d_seq_off.alloc((size_t)db->n_seq + 1);
 	if (rc == 0)
-		rc = db->d_blk_subj.alloc(((size_t)db->n_bases + 63) / 64 + 1);
+		rc = db->d_blk_subj.alloc(((size_t)db->n_bases >> kBlkShift) + 2);
 	if (rc == 0)
 		rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
 	if (rc == 0)

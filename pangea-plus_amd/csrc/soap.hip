@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_soap_search(SoapView db, const uint64_t
 						c1 += nm == 1;
 						c2 += nm == 2;
 					} else if ((uint32_t)nm == best) {
-						uint32_t s = db.blk_subj[(uint64_t)gp >> 6];
+						uint32_t s = db.blk_subj[(uint64_t)gp >> kBlkShift];
 						while (db.seq_off[s + 1] <= (uint64_t)gp)
 							s++;
 						SoapHit h;
