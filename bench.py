@@ -116,24 +116,22 @@ def main():
         t_index = time.time() - t0
         t_bcast = 0.0
         if world > 1:
-            shape = [db.shape() if rank == 0 else None]
-            dist.broadcast_object_list(shape, src=0)
-            if rank != 0:
-                db = pg.Db.alloc_like(shape[0])
+            from pangea_plus_amd import sharding
             torch.cuda.synchronize()
             t0 = time.time()
-            for name, view in db.device_arrays():
-                t = torch.as_tensor(view, device=dev)  # zero-copy alias of library-owned HBM
-                dist.broadcast(t, src=0)
+            db = sharding.broadcast_database(
+                db if rank == 0 else None, rank, world, dist, pg.Db.alloc_like,
+                # zero-copy aliases of library-owned HBM
+                lambda d: [(n, torch.as_tensor(v, device=dev)) for n, v in d.device_arrays()],
+                lambda d: d.finish_import())
             torch.cuda.synchronize()
             t_bcast = time.time() - t0
-            if rank != 0:
-                db.finish_import()
         db.bind_taxonomy(tax)
+        from pangea_plus_amd.sharding import batch_first_read as sharding_first
         B = args.reads
         batches = []
         for s in range(args.warmup + args.steps):
-            first = (s * world + rank) * B
+            first = sharding_first(s, rank, world, B)
             reads = pg.Reads.from_synth(cfg, first, B)
             rdp = pg.Rdp.from_synth(cfg, first, B, db)
             batches.append((reads, rdp))

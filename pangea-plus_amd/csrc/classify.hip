@@ -83,17 +83,44 @@ __device__ __forceinline__ uint64_t compress_even(uint64_t x)
 template <bool AMB> struct DenseMask {
 	uint64_t m0, m1, m2;
 	int lo, hi;
+	// The database and read arrays carry 8 spare words on either side, so the 6 read words and 7 database
+	// words of the diagonal are fetched without per-word range checks (all loads independent); the subject
+	// and read bounds are applied afterwards on the dense flags.
 	__device__ __forceinline__ void build(const Diag &D)
 	{
 		lo = D.lo;
 		hi = D.hi;
-		uint64_t d[6];
+		const int64_t wi = D.dstart >> 5;
+		const int sh = (int)(D.dstart & 31) * 2;
+		uint64_t dbv[7], rwv[6];
+#pragma unroll
+		for (int w = 0; w < 7; w++)
+			dbv[w] = D.dbw[wi + w];
 #pragma unroll
 		for (int w = 0; w < 6; w++)
-			d[w] = compress_even(mmw<AMB>(D, w));
+			rwv[w] = D.rw[w];
+		uint64_t d[6];
+#pragma unroll
+		for (int w = 0; w < 6; w++) {
+			const uint64_t win = sh ? (dbv[w] >> sh) | (dbv[w + 1] << (64 - sh)) : dbv[w];
+			const uint64_t x = rwv[w] ^ win;
+			uint64_t m = (x | (x >> 1)) & kEven;
+			if (AMB) {
+				if (D.ra)
+					m |= D.ra[w];
+				if (D.dba)
+					m |= window64(D.dba, D.dstart + 32 * w);
+			}
+			d[w] = compress_even(m);
+		}
 		m0 = d[0] | (d[1] << 32);
 		m1 = d[2] | (d[3] << 32);
 		m2 = d[4] | (d[5] << 32);
+		// flag everything outside [lo, hi)
+		auto below = [](int n) -> uint64_t { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); };
+		m0 |= below(lo) | ~below(hi);
+		m1 |= below(lo - 64) | ~below(hi - 64);
+		m2 |= below(lo - 128) | ~below(hi - 128);
 	}
 	// smallest flagged position >= pos, or hi
 	__device__ __forceinline__ int first_ge(int pos) const

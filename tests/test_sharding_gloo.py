@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: two gloo ranks run the same sharding/broadcast code bench.py runs over RCCL."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeDb:
+    """Stands in for a device database: same shape()/arrays protocol, CPU tensors."""
+
+    def __init__(self, shape, fill):
+        self._shape = shape
+        g = torch.Generator().manual_seed(1234)
+        self.arrays = [("words", torch.randint(0, 255, (shape[1] // 4,), dtype=torch.uint8, generator=g)),
+                       ("seq_off", torch.arange(shape[0] + 1, dtype=torch.int32).view(torch.uint8)),
+                       ("postings", torch.randint(0, 255, (shape[4] * 4,), dtype=torch.uint8, generator=g))]
+        if not fill:
+            self.arrays = [(n, torch.zeros_like(t)) for n, t in self.arrays]
+        self.imported = False
+
+    def shape(self):
+        return self._shape
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from pangea_plus_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shape = (100, 4000, 0, 22, 3985, 1)
+        src = FakeDb(shape, fill=True) if rank == 0 else None
+
+        def finish(d):
+            d.imported = True
+        db = sharding.broadcast_database(src, rank, world, dist, lambda s: FakeDb(s, fill=False),
+                                         lambda d: d.arrays, finish)
+        ref = FakeDb(shape, fill=True)
+        ok = db.shape() == shape and all(torch.equal(a[1], b[1]) for a, b in zip(db.arrays, ref.arrays))
+        ok = ok and (rank == 0 or db.imported)
+        # read sharding: each rank "classifies" its block; rank 0 concatenates in rank order
+        total = 1003
+        lo, hi = sharding.block_range(total, rank, world)
+        local = b"".join(b"r%d\thit\n" % i for i in range(lo, hi))
+        whole = sharding.gather_in_rank_order(local, rank, world, dist)
+        if rank == 0:
+            ok = ok and whole == b"".join(b"r%d\thit\n" % i for i in range(total))
+        # weak-scaling batches never overlap
+        firsts = [sharding.batch_first_read(s, rank, world, 10) for s in range(3)]
+        allf = [None] * world
+        dist.all_gather_object(allf, firsts)
+        flat = sorted(x for f in allf for x in f)
+        ok = ok and flat == [10 * k for k in range(3 * world)]
+        open(os.path.join(out_dir, "rank%d.ok" % rank), "w").write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
+    world = 2
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / ("rank%d.ok" % r)).read_text() == "1"
+
+
+def test_block_range_matches_cli_partition():
+    sys.path.insert(0, ROOT)
+    from pangea_plus_amd import sharding
+    for total in (0, 1, 7, 1003):
+        for world in (1, 2, 3, 8):
+            cuts = [sharding.block_range(total, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))

@@ -1,4 +1,5 @@
-import os, sys, time
+"""Profiling aid: stage-truncated timing of k_seed_extend (PGX_SEED_STOP) at full scale."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pangea_plus_amd as pg
 from pangea_plus_amd import _capi
@@ -10,4 +11,4 @@ for stop in (1, 2, 3, 0):
     os.environ["PGX_SEED_STOP"] = str(stop)
     for it in range(2):
         h = _capi.blast_search(db, reads); st = _capi.stage_times(); del h
-    print("stop=%d seed_extend=%.1f ms  sort=%.1f hits=%d" % (stop, st.seed_extend_ms, st.sort_ms, st.hits), flush=True)
+    print("stop=%d seed_extend=%.1f ms sort=%.1f ms hits=%d" % (stop, st.seed_extend_ms, st.sort_ms, st.hits), flush=True)
