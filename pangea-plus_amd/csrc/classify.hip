@@ -81,6 +81,7 @@ __device__ __forceinline__ uint64_t compress_even(uint64_t x)
 //              once (5 read words + 5 database windows for a 150-bp read); every scan is bit logic
 //   LazyMask   any length: 32-base words rebuilt on demand (loads served by L1/L2)
 template <bool AMB> struct DenseMask {
+	static constexpr bool kHasWindows = true;
 	uint64_t m0, m1, m2;
 	int lo, hi;
 	// The database and read arrays carry 8 spare words on either side, so the 6 read words and 7 database
@@ -122,6 +123,50 @@ template <bool AMB> struct DenseMask {
 		m1 |= below(lo - 64) | ~below(hi - 64);
 		m2 |= below(lo - 128) | ~below(hi - 128);
 	}
+	// w[i] set iff positions i .. i+27 all match (a 28-window of matches starts at i): log-step doubling
+	// 2,4,8,16 then 16+8 and 24+4; every exact run >= 28 shows up as a run of set bits from its start
+	struct Win {
+		uint64_t w0, w1, w2;
+	};
+	__device__ __forceinline__ Win seed_windows() const
+	{
+		uint64_t r0 = ~m0, r1 = ~m1, r2 = ~m2;
+#define PGX_SHR(k, a0, a1, a2, o0, o1, o2)                                                                             \
+		const uint64_t o0 = ((a0) >> (k)) | ((a1) << (64 - (k))), o1 = ((a1) >> (k)) | ((a2) << (64 - (k))),   \
+			       o2 = (a2) >> (k);
+		PGX_SHR(1, r0, r1, r2, s0, s1, s2)
+		const uint64_t a20 = r0 & s0, a21 = r1 & s1, a22 = r2 & s2;
+		PGX_SHR(2, a20, a21, a22, t0, t1, t2)
+		const uint64_t a40 = a20 & t0, a41 = a21 & t1, a42 = a22 & t2;
+		PGX_SHR(4, a40, a41, a42, u0, u1, u2)
+		const uint64_t a80 = a40 & u0, a81 = a41 & u1, a82 = a42 & u2;
+		PGX_SHR(8, a80, a81, a82, v0, v1, v2)
+		const uint64_t b0 = a80 & v0, b1 = a81 & v1, b2 = a82 & v2; // 16
+		PGX_SHR(16, a80, a81, a82, x0, x1, x2)
+		const uint64_t c0 = b0 & x0, c1 = b1 & x1, c2 = b2 & x2; // 24
+		PGX_SHR(24, a40, a41, a42, y0, y1, y2)
+#undef PGX_SHR
+		Win w;
+		w.w0 = c0 & y0; // 28
+		w.w1 = c1 & y1;
+		w.w2 = c2 & y2;
+		return w;
+	}
+	// is any window bit set below position n?
+	__device__ __forceinline__ static bool win_any_below(const Win &w, int n)
+	{
+		auto below = [](int k) -> uint64_t { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1)); };
+		return ((w.w0 & below(n)) | (w.w1 & below(n - 64)) | (w.w2 & below(n - 128))) != 0;
+	}
+	// lowest window bit at position >= n, or 192
+	__device__ __forceinline__ static int win_first_ge(const Win &w, int n)
+	{
+		const uint64_t a0 = n < 64 ? w.w0 & (n <= 0 ? ~0ull : (~0ull << n)) : 0ull;
+		const uint64_t a1 = n < 64 ? w.w1 : (n < 128 ? w.w1 & (~0ull << (n - 64)) : 0ull);
+		const uint64_t a2 = n < 128 ? w.w2 : (n < 192 ? w.w2 & (~0ull << (n - 128)) : 0ull);
+		return a0 ? __ffsll((unsigned long long)a0) - 1
+			  : (a1 ? 63 + __ffsll((unsigned long long)a1) : (a2 ? 127 + __ffsll((unsigned long long)a2) : 192));
+	}
 	// smallest flagged position >= pos, or hi
 	__device__ __forceinline__ int first_ge(int pos) const
 	{
@@ -148,6 +193,9 @@ template <bool AMB> struct DenseMask {
 };
 
 template <bool AMB> struct LazyMask {
+	static constexpr bool kHasWindows = false;
+	struct Win {
+	};
 	Diag D;
 	int lo, hi;
 	__device__ __forceinline__ void build(const Diag &d)
@@ -206,8 +254,12 @@ struct WaveLds {
 struct OutView {
 	pgx_hit *main, *ovf;
 	unsigned long long main_cap, ovf_cap;
-	unsigned long long *counters; // [0] main hits, [1] probes, [2] postings, [3] seed runs, [4] overflow hits
+	// [0] main-table slots reserved (chunks), [1] probes, [2] postings, [3] seed runs, [4] overflow hits,
+	// [5] hits stored in the main table
+	unsigned long long *counters;
 };
+constexpr unsigned int kChunk = 2048; // main-table slots a wave reserves with one atomic (a single hot counter
+				      // sustains only ~90 M atomics/s: one per read would cost more than the search)
 
 __device__ __forceinline__ void emit_hit(WaveLds *st, const OutView &ov, const pgx_hit &h)
 {
@@ -242,6 +294,10 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	D.hi = hi64 < L ? (int)hi64 : L;
 	Mask M;
 	M.build(D);
+	if (db.dbg_stop == 4) {
+		n_runs += (unsigned long long)(M.first_ge(qp) & 1);
+		return;
+	}
 
 	// (1) only the left-most probe inside an exact run reports that run
 	const int lm = M.last_lt(qp);
@@ -255,14 +311,26 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	if (re - run_start < kWord)
 		return;
 	n_runs++; // a >= 28 exact run reached through its left-most probe
+	if (db.dbg_stop == 5)
+		return;
 	// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
-	int pos = D.lo;
-	while (pos < run_start) {
-		int m1 = M.first_ge(pos);
-		if (m1 - pos >= kWord)
+	int pos;
+	typename Mask::Win W;
+	if constexpr (Mask::kHasWindows) {
+		W = M.seed_windows();
+		if (Mask::win_any_below(W, run_start))
 			return;
-		pos = m1 + 1;
+	} else {
+		pos = D.lo;
+		while (pos < run_start) {
+			int m1 = M.first_ge(pos);
+			if (m1 - pos >= kWord)
+				return;
+			pos = m1 + 1;
+		}
 	}
+	if (db.dbg_stop == 6)
+		return;
 	// (4) spec S3: seeds left to right, X-drop extension on the mismatch flags
 	int covered = D.lo;
 	pos = run_start;
@@ -327,10 +395,14 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				h.sstart = (int32_t)sr;
 				h.send = (int32_t)sl;
 			}
-			emit_hit(st, ov, h);
+			if (db.dbg_stop != 7)
+				emit_hit(st, ov, h);
 			covered = br + 1;
 		}
-		pos = e + 1;
+		if constexpr (Mask::kHasWindows)
+			pos = Mask::win_first_ge(W, covered > e ? covered : e + 1); // next seed run (a run start)
+		else
+			pos = covered > e + 1 ? covered : e + 1;
 	}
 }
 
@@ -359,7 +431,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	__shared__ WaveLds s_lds[kWavesPerBlock];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds *st = &s_lds[wave];
-	unsigned long long n_probe = 0, n_post = 0, n_runs = 0;
+	unsigned long long n_probe = 0, n_post = 0, n_runs = 0, n_main = 0;
+	unsigned long long chunk_base = 0;
+	unsigned int chunk_used = kChunk; // forces a reservation at the first flush
 	const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
 	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
@@ -548,9 +622,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 		uint32_t start = kFragmented;
 		if (n) {
 			unsigned long long base = 0;
-			if (lane == 0)
-				base = atomicAdd(&ov.counters[frag ? 4 : 0], (unsigned long long)n);
-			base = __shfl(base, 0);
+			if (frag) {
+				if (lane == 0)
+					base = atomicAdd(&ov.counters[4], (unsigned long long)n);
+				base = __shfl(base, 0);
+			} else {
+				// sub-allocate from the wave's chunk of the main table
+				if (chunk_used + n > kChunk) {
+					if (lane == 0)
+						chunk_base = atomicAdd(&ov.counters[0], (unsigned long long)kChunk);
+					chunk_base = __shfl(chunk_base, 0);
+					chunk_used = 0;
+				}
+				base = chunk_base + chunk_used;
+				chunk_used += n;
+				n_main += lane == 0 ? n : 0;
+			}
 			pgx_hit *dst = frag ? ov.ovf : ov.main;
 			const unsigned long long dcap = frag ? ov.ovf_cap : ov.main_cap;
 			for (unsigned int i = lane; i < n; i += 64)
@@ -574,6 +661,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 		n_runs += __shfl_down(n_runs, d);
 	}
 	if (lane == 0) {
+		atomicAdd(&ov.counters[5], n_main);
 		atomicAdd(&ov.counters[1], n_probe);
 		atomicAdd(&ov.counters[2], n_post);
 		atomicAdd(&ov.counters[3], n_runs);
@@ -1042,7 +1130,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 
 	// seed + extend: unfragmented reads land contiguously in `scratch`, the rest in `ovf`;
 	// grow and repeat if a guess was too small
-	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(n * 40, 1 << 16), g_ws.hit_cap_hint);
+	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(n * 40, 1 << 16) + (uint64_t)grid * kWavesPerBlock * kChunk, g_ws.hit_cap_hint);
 	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(n / 4, 1 << 16), g_ws.ovf_cap_hint);
 	DevBuf<pgx_hit> &scratch = g_ws.scratch, &ovf = g_ws.ovf;
 	DevBuf<uint32_t> &read_start = g_ws.read_start;
@@ -1079,8 +1167,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		cap = std::max<uint64_t>(cap, h_cnt[0] + h_cnt[0] / 8);
 		ovf_cap = std::max<uint64_t>(ovf_cap, h_cnt[4] + h_cnt[4] / 8);
 	}
-	const uint64_t H_main = h_cnt[0], H_ovf = h_cnt[4], H = H_main + H_ovf;
-	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, H_main + H_main / 16);
+	// h_cnt[0] counts reserved slots (chunks), h_cnt[5] the hits actually stored there
+	const uint64_t H_main = h_cnt[5], H_ovf = h_cnt[4], H = H_main + H_ovf;
+	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, h_cnt[0] + h_cnt[0] / 16);
 	g_ws.ovf_cap_hint = std::max<uint64_t>(g_ws.ovf_cap_hint, H_ovf + H_ovf / 16);
 	out->n_hits = (int64_t)H;
 	g_times.hits = (int64_t)H;
