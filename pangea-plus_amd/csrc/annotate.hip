@@ -455,6 +455,15 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	db->simrank_zero = rank["0"];
 	PGX_TRY(db->d_simrank_lut.alloc(lut.size()));
 	PGX_TRY(db->d_simrank_lut.upload(lut.data(), lut.size()));
+	{
+		// short alignments: skip the divisions, one table read gives the rank of the pident text
+		std::vector<uint32_t> byl(256 * 256, 0);
+		for (int len = 1; len < 256; len++)
+			for (int mm = 0; mm <= len; mm++)
+				byl[(size_t)len * 256 + (size_t)mm] = lut[(size_t)pident_hundredths(len - mm, len)];
+		PGX_TRY(db->d_simrank_len.alloc(byl.size()));
+		PGX_TRY(db->d_simrank_len.upload(byl.data(), byl.size()));
+	}
 	// taxid -> token id of its cleaned scientific name (what an RDP assignment of that node would carry)
 	std::vector<uint32_t> nn(tax->n_nodes + 1, 0);
 	{

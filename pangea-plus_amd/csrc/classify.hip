@@ -787,6 +787,7 @@ struct ConsView {
 	const uint32_t *subj_tok_off, *subj_tok; // per subject token ids
 	const int8_t *tok_rank;                  // token id -> index in "0".."6" or -1
 	const uint32_t *simrank_lut;             // pident hundredths -> string-order rank
+	const uint32_t *simrank_len;             // [length * 256 + mismatches] for alignments < 256 long
 	uint32_t simrank_undef, simrank_zero;
 	const uint32_t *rdp_off, *rdp_name;
 	const int8_t *rdp_rank;
@@ -794,6 +795,15 @@ struct ConsView {
 	const uint32_t *subj_pairs; // 16 words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
 	const uint32_t *rdp_code;   // name << 3 | rank + 1 per RDP triplet
 };
+
+// string-order rank of the hit's pident text
+__device__ __forceinline__ uint32_t hit_simrank(const ConsView &cv, const pgx_hit &h)
+{
+	const int len = h.qend - h.qstart + 1;
+	if (len < 256)
+		return cv.simrank_len[len * 256 + h.mismatch];
+	return cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
+}
 
 constexpr int kRdpRegs = 8; // RDP triplets of a read kept in registers by the fast agreement count
 
@@ -834,12 +844,46 @@ __device__ __forceinline__ uint32_t hit_rank_matches(const ConsView &cv, uint32_
 	return rank_matches(cv.subj_tok + t0, nt, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
 }
 
-constexpr int kSortCap = 256; // hits of one read held in LDS by its wave
+constexpr int kSortCap = 64; // hits of one read ordered by its wave: one hit per lane
 
+// S5 order as three integers compared lexicographically (reads up to 65 535 bases; longer reads take the
+// field-by-field comparison of the big-read path)
+struct SortKey {
+	uint64_t k1, k2;
+	uint32_t k3;
+};
+__device__ __forceinline__ SortKey make_key(const pgx_hit &h, int best)
+{
+	SortKey k;
+	k.k1 = ((uint64_t)(0xFFFF - best) << 48) | ((uint64_t)(uint32_t)h.subject << 16) | (uint64_t)(0xFFFF - h.score);
+	k.k2 = ((uint64_t)(uint32_t)h.qstart << 48) | ((uint64_t)(uint32_t)h.qend << 32) | (uint64_t)(uint32_t)h.sstart;
+	k.k3 = (uint32_t)h.send;
+	return k;
+}
+__device__ __forceinline__ bool key_less(const SortKey &a, const SortKey &b)
+{
+	if (a.k1 != b.k1)
+		return a.k1 < b.k1;
+	if (a.k2 != b.k2)
+		return a.k2 < b.k2;
+	return a.k3 < b.k3;
+}
+
+// LDS of one wave.  Phase A holds (subject, score) pairs then the sort keys; phase B (after every lane has
+// its rank) reuses the same bytes for the per-rank consensus inputs.  3 KB per wave keeps the kernel at the
+// register-limited occupancy: it is bound by the latency of its gathers, not by arithmetic.
 struct SortWave {
-	pgx_hit hit[kSortCap];
-	int best[kSortCap];
-	uint32_t rm[kSortCap], ntok[kSortCap], sim[kSortCap]; // indexed by final rank
+	union {
+		struct {
+			uint64_t k1[kSortCap], k2[kSortCap];
+			uint32_t k3[kSortCap];
+			int subj[kSortCap], score[kSortCap];
+		} a;
+		struct {
+			uint64_t krm[kSortCap], kcnt[kSortCap]; // text-order keys of the agreement and token counts
+			uint32_t rm[kSortCap], sim[kSortCap];
+		} b;
+	};
 };
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit *__restrict__ hits,
@@ -847,13 +891,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 									 const uint32_t *__restrict__ read_start,
 									 const uint32_t *__restrict__ off,
 									 uint32_t *__restrict__ read_cnt, uint32_t n_reads,
-									 ConsView cv, int do_consensus,
+									 ConsView cv, int do_consensus, int lds_ok,
 									 pgx_consensus_rec *__restrict__ recs,
 									 uint32_t *__restrict__ big_list,
 									 uint32_t *__restrict__ big_count)
 {
-	extern __shared__ unsigned char s_raw[];
-	SortWave *sw = reinterpret_cast<SortWave *>(s_raw) + (threadIdx.x >> 6);
+	__shared__ SortWave s_sw[kWavesPerBlock];
+	SortWave *sw = &s_sw[threadIdx.x >> 6];
 	const int lane = threadIdx.x & 63;
 	for (uint32_t r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); r < n_reads; r += gridDim.x * kWavesPerBlock) {
 		const uint32_t o = off[r], n = off[r + 1] - o;
@@ -864,7 +908,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 			}
 			continue;
 		}
-		if (n > (uint32_t)kSortCap) {
+		if (n > (uint32_t)kSortCap || !lds_ok) {
 			if (lane == 0)
 				big_list[atomicAdd(big_count, 1u)] = r;
 			continue;
@@ -872,8 +916,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
 		const uint32_t st0 = read_start[r];
 		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
-		for (uint32_t i = lane; i < n; i += 64)
-			sw->hit[i] = src[i];
+		const bool mine = (uint32_t)lane < n;
+		pgx_hit h;
+		if (mine) {
+			h = src[lane];
+			sw->a.subj[lane] = h.subject;
+			sw->a.score[lane] = h.score;
+		}
 		// the read's RDP codes, wave-uniform, in registers (slots past the end match nothing)
 		uint32_t rcode[kRdpRegs], rdp0 = 0, rdp1 = 0;
 		if (do_consensus) {
@@ -884,35 +933,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 				rcode[b] = rdp0 + b < rdp1 ? cv.rdp_code[rdp0 + b] : 0xFFFFFFFEu;
 		}
 		lds_fence();
-		// best score of each hit's subject
-		for (uint32_t i = lane; i < n; i += 64) {
-			const int subj = sw->hit[i].subject;
-			int b = sw->hit[i].score;
+		// best score of the hit's subject
+		int best = 0;
+		if (mine) {
+			best = h.score;
 			for (uint32_t j = 0; j < n; j++)
-				if (sw->hit[j].subject == subj && sw->hit[j].score > b)
-					b = sw->hit[j].score;
-			sw->best[i] = b;
+				if (sw->a.subj[j] == h.subject && sw->a.score[j] > best)
+					best = sw->a.score[j];
+		}
+		SortKey kx = make_key(h, best);
+		if (mine) {
+			sw->a.k1[lane] = kx.k1;
+			sw->a.k2[lane] = kx.k2;
+			sw->a.k3[lane] = kx.k3;
 		}
 		lds_fence();
 		// rank = number of hits that precede this one
-		for (uint32_t i = lane; i < n; i += 64) {
-			const pgx_hit h = sw->hit[i];
-			const int b = sw->best[i];
-			uint32_t rank = 0;
-			for (uint32_t j = 0; j < n; j++)
-				rank += (j != i) && (hit_less(sw->hit[j], sw->best[j], h, b) ||
-						     (!hit_less(h, b, sw->hit[j], sw->best[j]) && j < i));
-			hits[o + rank] = h;
-			if (do_consensus) {
-				uint32_t ntok;
-				sw->rm[rank] = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
-				sw->ntok[rank] = ntok;
-				const int len = h.qend - h.qstart + 1;
-				sw->sim[rank] = cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
+		uint32_t rank = 0;
+		if (mine) {
+			for (uint32_t j = 0; j < n; j++) {
+				SortKey kj;
+				kj.k1 = sw->a.k1[j];
+				kj.k2 = sw->a.k2[j];
+				kj.k3 = sw->a.k3[j];
+				rank += key_less(kj, kx) || (!key_less(kx, kj) && j < (uint32_t)lane);
 			}
+			hits[o + rank] = h;
+		}
+		if (!do_consensus)
+			continue;
+		uint32_t rmv = 0, ntok = 0, sim = 0;
+		if (mine) {
+			rmv = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
+			sim = hit_simrank(cv, h);
+		}
+		lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
+		if (mine) {
+			sw->b.rm[rank] = rmv;
+			sw->b.sim[rank] = sim;
+			sw->b.krm[rank] = dec_str_key(rmv);
+			sw->b.kcnt[rank] = dec_str_key(ntok);
 		}
 		lds_fence();
-		if (do_consensus && lane == 0) {
+		if (lane == 0) {
 			// Consensus:186-204, strictly in table order
 			pgx_consensus_rec rec;
 			rec.hit = -1;
@@ -923,7 +986,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit 
 				ArgmaxState am;
 				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
 				for (uint32_t k = 0; k < n; k++)
-					am.step((int32_t)(o + k), sw->rm[k], sw->ntok[k], sw->sim[k]);
+					am.step_keys((int32_t)(o + k), sw->b.rm[k], sw->b.krm[k], sw->b.kcnt[k], sw->b.sim[k]);
 				rec.hit = am.win;
 				rec.matches = (int32_t)am.maxrm;
 			}
@@ -1005,8 +1068,7 @@ __global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint3
 			const pgx_hit h = hits[o + k];
 			uint32_t c;
 			const uint32_t rm = hit_rank_matches(cv, (uint32_t)h.subject, r0, r1, &c);
-			const int len = h.qend - h.qstart + 1;
-			am.step((int32_t)(o + k), rm, c, cv.simrank_lut[pident_hundredths(len - h.mismatch, len)]);
+			am.step((int32_t)(o + k), rm, c, hit_simrank(cv, h));
 		}
 		rec.hit = am.win;
 		rec.matches = (int32_t)am.maxrm;
@@ -1055,6 +1117,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 		cv.tok_rank = db->d_tok_rank.data();
 		cv.subj_pairs = db->d_subj_pairs.data();
 		cv.simrank_lut = db->d_simrank_lut.data();
+		cv.simrank_len = db->d_simrank_len.data();
 		cv.simrank_undef = db->simrank_undef;
 		cv.simrank_zero = db->simrank_zero;
 	}
@@ -1208,9 +1271,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_TRY(big_count.ensure(1));
 	PGX_HIP(hipMemsetAsync(big_count.data(), 0, sizeof(uint32_t), 0));
 	const ConsView cv = cons_view(db, rdp);
-	const size_t lds = sizeof(SortWave) * kWavesPerBlock;
-	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), lds, 0, out->d_hits.data(), scratch.data(),
-			   read_start.data(), out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, d_recs,
+	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
+			   read_start.data(), out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, rd->max_len <= 65535 ? 1 : 0, d_recs,
 			   big_list.data(), big_count.data());
 	PGX_HIP(hipGetLastError());
 	uint32_t n_big = 0;

@@ -45,6 +45,7 @@ struct pgx_db {
 	std::vector<int32_t> subj_taxid;
 	pgx::DevBuf<uint32_t> d_node_name_tok;       // taxid -> token id of a one-word scientific name (else 0)
 	pgx::DevBuf<uint32_t> d_simrank_lut;         // pident hundredths -> string-order rank
+	pgx::DevBuf<uint32_t> d_simrank_len;         // [length * 256 + mismatches] -> the same rank, alignments < 256 long
 	uint32_t simrank_undef = 0, simrank_zero = 0;
 	uint32_t intern(const std::string &s);
 };
