@@ -406,11 +406,15 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	}
 }
 
+// All LDS traffic of these kernels is wave-private (each wave owns its slice), and a wave's LDS operations
+// execute in issue order.  The fence therefore only has to stop the compiler from moving memory operations
+// across it and to drain the wave's own LDS queue; it deliberately does NOT wait for outstanding global
+// loads/stores (a workgroup-scope release would: `s_waitcnt vmcnt(0)` after every flush exposes the full
+// store latency once per read).
 __device__ __forceinline__ void lds_fence()
 {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // Seed + extend.  Per read (one wavefront):
@@ -886,7 +890,7 @@ struct SortWave {
 	};
 };
 
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_sort_consensus(pgx_hit *__restrict__ hits,
+__global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_hit *__restrict__ hits,
 									 const pgx_hit *__restrict__ scratch,
 									 const uint32_t *__restrict__ read_start,
 									 const uint32_t *__restrict__ off,
