@@ -28,8 +28,18 @@ static double now_s(void)
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+int o_bench_chain_files(const o_synth_cfg *cfg, int64_t first, int64_t n_reads, int threads, const char *taxdir,
+			o_bench_result *res, const char *hits_out, const char *cons_out);
+
 int o_bench_chain(const o_synth_cfg *cfg, int64_t first, int64_t n_reads, int threads, const char *taxdir,
 		  o_bench_result *res)
+{
+	return o_bench_chain_files(cfg, first, n_reads, threads, taxdir, res, NULL, NULL);
+}
+
+/* same chain; optionally leaves the -outfmt 6 table and the consensus text in files (full-size parity tests) */
+int o_bench_chain_files(const o_synth_cfg *cfg, int64_t first, int64_t n_reads, int threads, const char *taxdir,
+			o_bench_result *res, const char *hits_out, const char *cons_out)
 {
 	memset(res, 0, sizeof *res);
 	res->threads = threads;
@@ -111,6 +121,10 @@ int o_bench_chain(const o_synth_cfg *cfg, int64_t first, int64_t n_reads, int th
 		if (cons.p[i] == '\n' && cons.p[i + 1] == '#')
 			res->consensus_records++;
 
+	if (hits_out)
+		obuf_write_file(&hits_txt, hits_out);
+	if (cons_out)
+		obuf_write_file(&cons, cons_out);
 	free(rdp);
 	obuf_free(&cons);
 	obuf_free(&log);

@@ -1,0 +1,101 @@
+"""GPU parity at BASELINE.json's full database size (1 Gbp, 666 667 subjects, direct-address 32-bit index):
+the fused pipeline against the oracle chain on a sample of the bench's own read stream, byte for byte, plus
+size-independent properties on a larger batch."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_seq", C.c_int64), ("seq_len", C.c_int32), ("n_genus", C.c_int64),
+                ("read_seed", C.c_uint64), ("read_len", C.c_int32)]
+
+
+class ORes(C.Structure):
+    _fields_ = [("gen_s", C.c_double), ("search_s", C.c_double), ("format_s", C.c_double), ("taxcollect_s", C.c_double),
+                ("consensus_s", C.c_double), ("reads", C.c_int64), ("hits", C.c_int64), ("recs", C.c_int64),
+                ("threads", C.c_int32)]
+
+
+@pytest.fixture(scope="module")
+def full(tmp_path_factory, oracle_bin):
+    import pangea_plus_amd as pg
+    from pangea_plus_amd import _capi
+    pg.init(0)
+    d = tmp_path_factory.mktemp("full")
+    cfg = pg.SynthCfg.default()
+    _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), str(d).encode()))
+    pg.TaxDb.create(str(d))
+    tax = pg.TaxDb.open(str(d))
+    db = pg.Db.from_synth(cfg)
+    assert db.shape()[3] == 32  # direct-address index
+    db.bind_taxonomy(tax)
+    return pg, _capi, cfg, db, d
+
+
+def test_full_size_sample_equals_oracle_chain(full, oracle_bin):
+    pg, _capi, cfg, db, d = full
+    first, n = 5_000_000, 1500  # a window in the middle of the bench's read stream
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    oc = OCfg(cfg.seed, cfg.n_seq, cfg.seq_len, cfg.n_genus, cfg.read_seed, cfg.read_len)
+    res = ORes()
+    lib.o_bench_chain_files.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p,
+                                        C.c_char_p]
+    hits_p, cons_p = str(d / "o_hits.tsv"), str(d / "o_cons.txt")
+    assert lib.o_bench_chain_files(C.byref(oc), first, n, min(os.cpu_count() or 1, 16), str(d).encode(), C.byref(res),
+                                   hits_p.encode(), cons_p.encode()) == 0
+    reads = pg.Reads.from_synth(cfg, first, n)
+    rdp = pg.Rdp.from_synth(cfg, first, n, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    assert res.hits == len(hits) > 20000
+    assert hits.format(db, reads) == open(hits_p, "rb").read()
+    assert _capi.consensus_format(db, reads, hits, recs) == open(cons_p, "rb").read()
+
+
+def test_full_size_properties(full):
+    pg, _capi, cfg, db, d = full
+    n = 300_000
+    reads = pg.Reads.from_synth(cfg, 0, n)
+    rdp = pg.Rdp.from_synth(cfg, 0, n, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    h = hits.to_numpy()
+    off = hits.read_offsets(n)
+    assert off[-1] == len(h) and (np.diff(off) >= 0).all()
+    length = h["qend"] - h["qstart"] + 1
+    # ungapped: score = matches - 2 mismatches, both spans equal, coordinates inside read and subject
+    assert (h["score"] == length - 3 * h["mismatch"]).all()
+    assert (np.abs(h["send"] - h["sstart"]) + 1 == length).all()
+    assert (h["qstart"] >= 1).all() and (h["qend"] <= cfg.read_len).all() and (length >= 28).all()
+    assert (np.minimum(h["sstart"], h["send"]) >= 1).all() and (np.maximum(h["sstart"], h["send"]) <= cfg.seq_len).all()
+    assert (h["subject"] >= 0).all() and (h["subject"] < cfg.n_seq).all()
+    # hits are grouped by read, in table order inside a read: best score of a subject never increases
+    read_of = np.repeat(np.arange(n), np.diff(off))
+    assert (h["read"] == read_of).all()
+    first_of_read = np.zeros(len(h), bool)
+    first_of_read[off[:-1][np.diff(off) > 0]] = True
+    new_subject = first_of_read | (h["subject"] != np.roll(h["subject"], 1))
+    lead = h["score"][new_subject]
+    lead_read = read_of[new_subject]
+    same = lead_read[1:] == lead_read[:-1]
+    assert (lead[1:][same] <= lead[:-1][same]).all()
+    # a read with an error-free stretch of >= 28 bases must find its source sequence: nearly every read does
+    has_hit = np.diff(off) > 0
+    assert has_hit.mean() > 0.98
+    # consensus: the winner is one of the read's own hits and agrees with RDP on at most the 6 ranks it carries
+    rh = recs["hit"]
+    ok = rh >= 0
+    assert (ok == has_hit).all()
+    assert (rh[ok] >= off[:-1][ok]).all() and (rh[ok] < off[1:][ok]).all()
+    assert recs["matches"].max() <= 6 and recs["matches"][ok].min() >= 0
+    # batch independence: the second half searched alone gives the same rows
+    half = pg.Reads.from_synth(cfg, n // 2, n - n // 2)
+    h2 = _capi.blast_search(db, half).to_numpy()
+    tail = h[off[n // 2]:].copy()
+    tail["read"] -= n // 2
+    assert (tail == h2).all()
