@@ -173,10 +173,10 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 	// read sharding (mpiblastn's static query partition, Scripts/submit_MPI-blast.job:24): this
 	// process takes block `rank` of `world_size` contiguous blocks
 	int ws = o->world_size > 0 ? o->world_size : 1, rk = o->rank;
-	pgx_reads *all = nullptr;
-	int rc = pgx_reads_from_fasta(o->query_path, 0, -1, &all);
-	int64_t total = rc == 0 ? all->n : 0;
-	pgx_reads_close(all);
+	int rc = 0;
+	const int64_t total = fasta_count_records(o->query_path);
+	if (total < 0)
+		rc = fail(PGX_E_IO, "cannot open query file %s", o->query_path);
 	pgx_reads *rd = nullptr;
 	if (rc == 0) {
 		int64_t lo = total * rk / ws, hi = total * (rk + 1) / ws;

@@ -91,6 +91,7 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 			pgx_reads **out);
 int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);
 int db_read_host(const char *prefix, pgx_db **out);
+int64_t fasta_count_records(const char *path);
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);
 

@@ -15,15 +15,45 @@
 namespace pgx {
 
 // ------------------------------------------------------------------------------------------ host packing
-static inline int base_code(unsigned char c)
+// FASTA text split on the host (memchr/memcpy speed): headers, per-sequence base offsets and the sequence
+// letters of all records back to back.  The 2-bit packing itself runs on the device (k_pack_*).
+struct FastaLetters {
+	std::vector<std::string> headers;
+	std::vector<uint64_t> off; // n+1 offsets into letters
+	std::string letters;
+};
+
+static void split_fasta_text(const std::string &text, FastaLetters &fl)
 {
-	switch (c) {
-	case 'A': case 'a': return 0;
-	case 'C': case 'c': return 1;
-	case 'G': case 'g': return 2;
-	case 'T': case 't': case 'U': case 'u': return 3;
-	default: return 4;
+	fl.off.push_back(0);
+	fl.letters.reserve(text.size());
+	bool in_seq = false;
+	const char *base = text.data();
+	size_t i = 0, n = text.size();
+	while (i < n) {
+		const char *nl = (const char *)memchr(base + i, '\n', n - i);
+		size_t e = nl ? (size_t)(nl - base) : n;
+		size_t ll = e - i;
+		if (ll && base[i + ll - 1] == '\r')
+			ll--;
+		if (ll && base[i] == '>') {
+			if (in_seq)
+				fl.off.push_back(fl.letters.size());
+			fl.headers.emplace_back(base + i + 1, ll - 1);
+			in_seq = true;
+		} else if (in_seq && ll) {
+			if (!memchr(base + i, ' ', ll) && !memchr(base + i, '\t', ll)) {
+				fl.letters.append(base + i, ll);
+			} else {
+				for (size_t k = 0; k < ll; k++)
+					if (base[i + k] != ' ' && base[i + k] != '\t')
+						fl.letters.push_back(base[i + k]);
+			}
+		}
+		i = e + 1;
 	}
+	if (in_seq)
+		fl.off.push_back(fl.letters.size());
 }
 
 struct PackedSet {
@@ -33,53 +63,107 @@ struct PackedSet {
 	bool any_amb = false;
 };
 
-// Sequences packed back to back (database layout).
+__device__ __forceinline__ uint32_t letter_code(unsigned char c)
+{
+	// A C G T/U (any case) = 0..3, everything else 4 (ambiguous)
+	const unsigned char u = c & 0xDF; // upper case
+	return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : (u == 'T' || u == 'U') ? 3u : 4u;
+}
+
+// database layout: word w packs letters [32w, 32w+32) of the concatenation
+__global__ void k_pack_db(const unsigned char *__restrict__ letters, uint64_t n, uint64_t *__restrict__ words,
+			  uint64_t *__restrict__ amb, uint64_t n_words, unsigned int *__restrict__ any_amb)
+{
+	uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words)
+		return;
+	uint64_t bits = 0, flags = 0;
+	for (int k = 0; k < 32; k++) {
+		const uint64_t i = w * 32 + k;
+		if (i >= n)
+			break;
+		const uint32_t c = letter_code(letters[i]);
+		if (c < 4)
+			bits |= (uint64_t)c << (2 * k);
+		else
+			flags |= 1ull << (2 * k);
+	}
+	words[w] = bits;
+	if (amb)
+		amb[w] = flags;
+	if (flags)
+		atomicOr(any_amb, 1u);
+}
+
+// read layout: every read starts on a word boundary; fold_to_g reads every ambiguous letter as G and counts them
+__global__ void k_pack_reads(const unsigned char *__restrict__ letters, const uint64_t *__restrict__ off,
+			     const uint32_t *__restrict__ woff, uint64_t n_reads, int fold_to_g, uint64_t *__restrict__ fwd,
+			     uint64_t *__restrict__ amb, uint32_t *__restrict__ amb_count, unsigned int *__restrict__ any_amb)
+{
+	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	const uint64_t s = off[r], L = off[r + 1] - s;
+	const uint32_t w0 = woff[r];
+	uint32_t namb = 0;
+	for (uint64_t w = 0; w * 32 < L; w++) {
+		uint64_t bits = 0, flags = 0;
+		for (int k = 0; k < 32; k++) {
+			const uint64_t i = w * 32 + k;
+			if (i >= L)
+				break;
+			uint32_t c = letter_code(letters[s + i]);
+			if (c >= 4) {
+				namb++;
+				if (fold_to_g)
+					c = 2;
+			}
+			if (c < 4)
+				bits |= (uint64_t)c << (2 * k);
+			else
+				flags |= 1ull << (2 * k);
+		}
+		fwd[w0 + w] = bits;
+		if (amb)
+			amb[w0 + w] = flags;
+	}
+	if (amb_count)
+		amb_count[r] = namb;
+	if (namb && !fold_to_g)
+		atomicOr(any_amb, 1u);
+}
+
+// FASTA text -> database packed on the device; result copied back into a PackedSet (the database keeps a
+// host copy for the .pgxdb file and for SOAP row formatting)
 static int pack_fasta_text(const std::string &text, PackedSet &ps)
 {
-	ps.off.push_back(0);
-	uint64_t total = 0;
-	bool in_seq = false;
-	size_t i = 0, n = text.size();
-	ps.words.reserve(n / 32 + 4);
-	auto put = [&](int code) {
-		size_t w = total >> 5;
-		if (w >= ps.words.size()) {
-			ps.words.push_back(0);
-			ps.amb.push_back(0);
-		}
-		int sh = (int)(total & 31) * 2;
-		if (code < 4) {
-			ps.words[w] |= (uint64_t)code << sh;
-		} else {
-			ps.amb[w] |= 1ull << sh;
-			ps.any_amb = true;
-		}
-		total++;
-	};
-	while (i < n) {
-		size_t e = text.find('\n', i);
-		if (e == std::string::npos)
-			e = n;
-		size_t ll = e - i;
-		if (ll && text[i + ll - 1] == '\r')
-			ll--;
-		if (ll && text[i] == '>') {
-			if (in_seq)
-				ps.off.push_back(total);
-			ps.headers.emplace_back(text, i + 1, ll - 1);
-			in_seq = true;
-		} else if (in_seq) {
-			for (size_t k = 0; k < ll; k++) {
-				unsigned char c = (unsigned char)text[i + k];
-				if (c == ' ' || c == '\t')
-					continue;
-				put(base_code(c));
-			}
-		}
-		i = e + 1;
-	}
-	if (in_seq)
-		ps.off.push_back(total);
+	FastaLetters fl;
+	split_fasta_text(text, fl);
+	ps.headers.swap(fl.headers);
+	ps.off.swap(fl.off);
+	const uint64_t n = fl.letters.size(), nw = (n + 31) / 32;
+	ps.words.assign(nw, 0);
+	ps.amb.assign(nw, 0);
+	ps.any_amb = false;
+	if (n == 0)
+		return 0;
+	PGX_TRY(require_device());
+	DevBuf<unsigned char> d_letters;
+	DevBuf<uint64_t> d_w, d_a;
+	DevBuf<unsigned int> d_flag;
+	PGX_TRY(d_letters.alloc(n));
+	PGX_TRY(d_letters.upload((const unsigned char *)fl.letters.data(), n));
+	PGX_TRY(d_w.alloc(nw));
+	PGX_TRY(d_a.alloc(nw));
+	PGX_TRY(d_flag.alloc(1, 0, 0, true));
+	hipLaunchKernelGGL(k_pack_db, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, d_letters.data(), n, d_w.data(), d_a.data(),
+			   nw, d_flag.data());
+	PGX_HIP(hipGetLastError());
+	unsigned int flag = 0;
+	PGX_TRY(d_flag.download(&flag, 1));
+	ps.any_amb = flag != 0;
+	PGX_TRY(d_w.download(ps.words.data(), nw));
+	PGX_TRY(d_a.download(ps.amb.data(), nw));
 	return 0;
 }
 
@@ -446,9 +530,11 @@ static int reads_finish(pgx_reads *rd)
 {
 	// d_fwd (and d_fwd_amb) are filled; build offsets/lengths on device and the rc strand
 	PGX_TRY(rd->d_len.alloc((size_t)rd->n));
-	PGX_TRY(rd->d_woff.alloc((size_t)rd->n + 1));
 	PGX_TRY(rd->d_len.upload(rd->h_len.data(), (size_t)rd->n));
-	PGX_TRY(rd->d_woff.upload(rd->h_woff.data(), (size_t)rd->n + 1));
+	if (!rd->d_woff.base) {
+		PGX_TRY(rd->d_woff.alloc((size_t)rd->n + 1));
+		PGX_TRY(rd->d_woff.upload(rd->h_woff.data(), (size_t)rd->n + 1));
+	}
 	PGX_TRY(rd->d_rc.alloc((size_t)rd->n_words + 8, 0, 0, true));
 	if (rd->n == 0)
 		return 0;
@@ -480,9 +566,11 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	std::string text = read_text_file(path, &ok);
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open query file %s", path);
-	PackedSet ps;
-	pack_fasta_text(text, ps);
-	int64_t total = (int64_t)ps.headers.size();
+	FastaLetters fl;
+	split_fasta_text(text, fl);
+	text.clear();
+	text.shrink_to_fit();
+	int64_t total = (int64_t)fl.headers.size();
 	if (first < 0)
 		first = 0;
 	if (first > total)
@@ -492,51 +580,60 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	pgx_reads *rd = new pgx_reads();
 	rd->n = count;
 	rd->first = first;
-	rd->has_amb = ps.any_amb && !fold_to_g;
 	rd->h_len.resize((size_t)count);
 	rd->h_woff.resize((size_t)count + 1);
-	if (amb_count)
-		amb_count->assign((size_t)count, 0);
 	uint64_t nw = 0;
+	rd->names.reserve((size_t)count);
 	for (int64_t i = 0; i < count; i++) {
-		uint64_t L = ps.off[(size_t)(first + i) + 1] - ps.off[(size_t)(first + i)];
+		uint64_t L = fl.off[(size_t)(first + i) + 1] - fl.off[(size_t)(first + i)];
 		rd->h_len[(size_t)i] = (uint32_t)L;
 		rd->h_woff[(size_t)i] = (uint32_t)nw;
 		nw += (L + 31) / 32;
 		if ((int32_t)L > rd->max_len)
 			rd->max_len = (int32_t)L;
-		rd->names.push_back(first_word(ps.headers[(size_t)(first + i)]));
+		rd->names.push_back(first_word(fl.headers[(size_t)(first + i)]));
 	}
 	rd->h_woff[(size_t)count] = (uint32_t)nw;
 	rd->n_words = (int64_t)nw;
-	// re-pack each read on its own word boundary
-	rd->h_fwd.assign(nw + 2, 0);
-	std::vector<uint64_t> fa(rd->has_amb ? nw + 2 : 0, 0);
-	auto get = [&](const std::vector<uint64_t> &src, uint64_t p) -> uint64_t {
-		return (src[p >> 5] >> (2 * (p & 31))) & 3;
-	};
-	for (int64_t i = 0; i < count; i++) {
-		uint64_t s = ps.off[(size_t)(first + i)], L = rd->h_len[(size_t)i], w0 = rd->h_woff[(size_t)i];
-		for (uint64_t k = 0; k < L; k++) {
-			uint64_t b = get(ps.words, s + k);
-			const bool amb = ps.any_amb && (get(ps.amb, s + k) & 1);
-			if (amb && fold_to_g) {
-				b = 2;
-				if (amb_count)
-					(*amb_count)[(size_t)i]++;
-			}
-			rd->h_fwd[w0 + (k >> 5)] |= b << (2 * (k & 31));
-			if (amb && rd->has_amb)
-				fa[w0 + (k >> 5)] |= 1ull << (2 * (k & 31));
-		}
+	// letters of the selected block go to the device as they are; the packing is a kernel
+	const uint64_t l0 = fl.off[(size_t)first], l1 = fl.off[(size_t)(first + count)];
+	std::vector<uint64_t> loff((size_t)count + 1);
+	for (int64_t i = 0; i <= count; i++)
+		loff[(size_t)i] = fl.off[(size_t)(first + i)] - l0;
+	DevBuf<unsigned char> d_letters;
+	DevBuf<uint64_t> d_loff;
+	DevBuf<uint32_t> d_namb;
+	DevBuf<unsigned int> d_flag;
+	int rc = d_letters.alloc(l1 - l0 ? l1 - l0 : 1);
+	if (rc == 0) rc = d_letters.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
+	if (rc == 0) rc = d_loff.alloc((size_t)count + 1);
+	if (rc == 0) rc = d_loff.upload(loff.data(), loff.size());
+	if (rc == 0) rc = d_namb.alloc(count ? (size_t)count : 1);
+	if (rc == 0) rc = d_flag.alloc(1, 0, 0, true);
+	if (rc == 0) rc = rd->d_woff.alloc((size_t)count + 1);
+	if (rc == 0) rc = rd->d_woff.upload(rd->h_woff.data(), (size_t)count + 1);
+	if (rc == 0) rc = rd->d_fwd.alloc((size_t)nw + 8, 0, 0, true);
+	if (rc == 0 && !fold_to_g) rc = rd->d_fwd_amb.alloc((size_t)nw + 8, 0, 0, true);
+	if (rc == 0 && count > 0) {
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, 0, d_letters.data(), d_loff.data(),
+				   rd->d_woff.data(), (uint64_t)count, fold_to_g ? 1 : 0, rd->d_fwd.data(),
+				   fold_to_g ? (uint64_t *)nullptr : rd->d_fwd_amb.data(), d_namb.data(), d_flag.data());
+		if (hipGetLastError() != hipSuccess)
+			rc = fail(PGX_E_NODEVICE, "k_pack_reads launch failed");
 	}
-	int rc = rd->d_fwd.alloc((size_t)nw + 8, 0, 0, true);
-	if (rc == 0)
-		rc = rd->d_fwd.upload(rd->h_fwd.data(), (size_t)nw);
-	if (rc == 0 && rd->has_amb) {
-		rc = rd->d_fwd_amb.alloc((size_t)nw + 8, 0, 0, true);
-		if (rc == 0)
-			rc = rd->d_fwd_amb.upload(fa.data(), (size_t)nw);
+	unsigned int flag = 0;
+	if (rc == 0) rc = d_flag.download(&flag, 1);
+	rd->has_amb = flag != 0 && !fold_to_g;
+	if (rc == 0 && !rd->has_amb)
+		rd->d_fwd_amb.release();
+	if (rc == 0 && amb_count) {
+		amb_count->assign((size_t)count, 0);
+		rc = d_namb.download(amb_count->data(), (size_t)count);
+	}
+	if (rc == 0 && fold_to_g) {
+		// SOAP row formatting echoes the read as aligned: keep a host copy of the packed forward strand
+		rd->h_fwd.assign(nw + 2, 0);
+		rc = rd->d_fwd.download(rd->h_fwd.data(), (size_t)nw);
 	}
 	if (rc == 0)
 		rc = reads_finish(rd);
@@ -571,6 +668,27 @@ int db_fold_amb_to_g(const pgx_db *src, pgx_db **out)
 }
 
 int db_read_host(const char *prefix, pgx_db **out) { return db_read_file(prefix, out); }
+
+// number of FASTA records of a file (lines starting with '>'), without packing anything
+int64_t fasta_count_records(const char *path)
+{
+	bool ok;
+	std::string text = read_text_file(path, &ok);
+	if (!ok)
+		return -1;
+	int64_t n = 0;
+	const char *base = text.data();
+	size_t i = 0, len = text.size();
+	while (i < len) {
+		if (base[i] == '>')
+			n++;
+		const char *nl = (const char *)memchr(base + i, '\n', len - i);
+		if (!nl)
+			break;
+		i = (size_t)(nl - base) + 1;
+	}
+	return n;
+}
 
 } // namespace pgx
 
