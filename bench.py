@@ -33,15 +33,16 @@ HBM_PEAK_GBS = 8000.0
 
 
 def algorithmic_bytes(n_reads, st, read_len):
-    """bytes k_seed_extend must move for one launch, from its own counters."""
+    """bytes k_seed_extend's algorithm has to move for one launch, each datum once at its
+    natural size, counted by the kernel's own counters."""
     words = (read_len + 31) // 32
-    per_read = 2 * 8 * words + 8            # both packed strands + length/offset
-    per_probe = 8                            # one bucket_off pair
-    per_posting = 4
-    per_run = 4 + 8 + 8 * (words + 1)        # blk_subj + seq_off pair + the database window of the diagonal
+    per_read = 2 * 8 * words + 8 + 4         # both packed strands, length/offset, per-read hit count
+    per_probe = 8                             # one bucket_off pair
+    per_posting = 4 + 4 + 4                   # posting, the 16-mer 13 bases to its left (duplicate filter), block-table entry
+    per_survivor = 8 + 8 * (words + 1)        # seq_off pair + the database window of the diagonal
     per_hit = 32
-    return (n_reads * per_read + st.probes * per_probe + st.postings * per_posting + st.candidates * per_run
-            + st.hits * per_hit + n_reads * 4)
+    return (n_reads * per_read + st.probes * per_probe + st.postings * per_posting + st.survivors * per_survivor
+            + st.hits * per_hit)
 
 
 def cpu_baseline(cfg, taxdir, sample):
@@ -190,7 +191,7 @@ def main():
                 "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "group": last.group_ms,
                                         "sort_consensus": last.sort_ms, "total": last.total_ms},
                 "per_read_last_step": {"probes": last.probes / B, "postings": last.postings / B,
-                                       "seed_runs": last.candidates / B, "hits": last.hits / B},
+                                       "filter_survivors": last.survivors / B, "seed_runs": last.candidates / B, "hits": last.hits / B},
                 "setup_s": {"db_generate_and_index": t_index, "index_broadcast": t_bcast},
             }
             if world == 1 and not args.no_cpu_baseline:

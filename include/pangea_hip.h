@@ -240,6 +240,7 @@ int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hit
 typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;
 	int64_t probes, postings, candidates, hits;
+	int64_t survivors; /* postings that pass the duplicate filter and get a diagonal mask built */
 } pgx_stage_times;
 int pgx_last_stage_times(pgx_stage_times *out);
 

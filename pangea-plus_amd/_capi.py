@@ -54,7 +54,7 @@ class SynthCfg(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [("seed_extend_ms", C.c_float), ("group_ms", C.c_float), ("sort_ms", C.c_float),
                 ("consensus_ms", C.c_float), ("total_ms", C.c_float), ("probes", C.c_int64), ("postings", C.c_int64),
-                ("candidates", C.c_int64), ("hits", C.c_int64)]
+                ("candidates", C.c_int64), ("hits", C.c_int64), ("survivors", C.c_int64)]
 
 
 class _DevArray(C.Structure):

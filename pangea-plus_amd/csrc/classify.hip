@@ -255,7 +255,7 @@ struct OutView {
 	pgx_hit *main, *ovf;
 	unsigned long long main_cap, ovf_cap;
 	// [0] main-table slots reserved (chunks), [1] probes, [2] postings, [3] seed runs, [4] overflow hits,
-	// [5] hits stored in the main table
+	// [5] hits stored in the main table, [6] candidates that survive the duplicate filter
 	unsigned long long *counters;
 };
 constexpr unsigned int kChunk = 2048; // main-table slots a wave reserves with one atomic (a single hot counter
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	__shared__ WaveLds s_lds[kWavesPerBlock];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	WaveLds *st = &s_lds[wave];
-	unsigned long long n_probe = 0, n_post = 0, n_runs = 0, n_main = 0;
+	unsigned long long n_probe = 0, n_post = 0, n_runs = 0, n_main = 0, n_surv = 0;
 	unsigned long long chunk_base = 0;
 	unsigned int chunk_used = kChunk; // forces a reservation at the first flush
 	const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 						st->qs1[slot] = s1[u];
 					}
 					q_n += (unsigned)__popcll(km);
+					n_surv += lane == 0 ? (unsigned long long)__popcll(km) : 0ull;
 				}
 				lds_fence();
 				while (q_n >= 64)
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 	}
 	if (lane == 0) {
 		atomicAdd(&ov.counters[5], n_main);
+		atomicAdd(&ov.counters[6], n_surv);
 		atomicAdd(&ov.counters[1], n_probe);
 		atomicAdd(&ov.counters[2], n_post);
 		atomicAdd(&ov.counters[3], n_runs);
@@ -1243,6 +1245,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	g_times.probes = (int64_t)h_cnt[1];
 	g_times.postings = (int64_t)h_cnt[2];
 	g_times.candidates = (int64_t)h_cnt[3];
+	g_times.survivors = (int64_t)h_cnt[6];
 	if (H >= (1ull << 32))
 		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
 			    (unsigned long long)H);
