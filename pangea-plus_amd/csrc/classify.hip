@@ -892,66 +892,81 @@ struct SortWave {
 	};
 };
 
+// G lanes per read: G = 32 orders two reads per wavefront (most reads have <= 32 hits), G = 64 one.  A read with
+// more than G hits is passed on through `next_list` (to the G = 64 launch, then to the big-read path).
+// `list`/`n_list_ptr`: optional indirection (read ids and their count in device memory); null = all reads.
+template <int G>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_hit *__restrict__ hits,
 									 const pgx_hit *__restrict__ scratch,
 									 const uint32_t *__restrict__ read_start,
-									 const uint32_t *__restrict__ off,
-									 uint32_t *__restrict__ read_cnt, uint32_t n_reads,
-									 ConsView cv, int do_consensus, int lds_ok,
+									 const uint32_t *__restrict__ off, uint32_t n_reads,
+									 const uint32_t *__restrict__ list,
+									 const uint32_t *__restrict__ n_list_ptr, ConsView cv,
+									 int do_consensus, int lds_ok,
 									 pgx_consensus_rec *__restrict__ recs,
-									 uint32_t *__restrict__ big_list,
-									 uint32_t *__restrict__ big_count)
+									 uint32_t *__restrict__ next_list,
+									 uint32_t *__restrict__ next_count)
 {
+	constexpr int RPW = 64 / G; // reads per wavefront
 	__shared__ SortWave s_sw[kWavesPerBlock];
 	SortWave *sw = &s_sw[threadIdx.x >> 6];
 	const int lane = threadIdx.x & 63;
-	for (uint32_t r = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); r < n_reads; r += gridDim.x * kWavesPerBlock) {
-		const uint32_t o = off[r], n = off[r + 1] - o;
-		if (n == 0) {
-			if (do_consensus && lane == 0) {
-				recs[r].hit = -2;
-				recs[r].matches = 0;
-			}
-			continue;
+	const int g = lane / G, li = lane % G, slot0 = g * G;
+	const uint32_t total = list ? *n_list_ptr : n_reads;
+	for (uint32_t base = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW; base < total;
+	     base += gridDim.x * kWavesPerBlock * RPW) {
+		const uint32_t idx = base + (uint32_t)g;
+		const bool valid = idx < total;
+		const uint32_t r = valid ? (list ? list[idx] : idx) : 0u;
+		const uint32_t o = valid ? off[r] : 0u;
+		uint32_t n = valid ? off[r + 1] - o : 0u;
+		if (valid && n == 0 && do_consensus && li == 0) {
+			recs[r].hit = -2;
+			recs[r].matches = 0;
 		}
-		if (n > (uint32_t)kSortCap || !lds_ok) {
-			if (lane == 0)
-				big_list[atomicAdd(big_count, 1u)] = r;
-			continue;
+		if (valid && (n > (uint32_t)G || !lds_ok)) {
+			if (li == 0)
+				next_list[atomicAdd(next_count, 1u)] = r;
+			n = 0; // not ours
 		}
 		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
-		const uint32_t st0 = read_start[r];
+		const uint32_t st0 = n ? read_start[r] : 0u;
 		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
-		const bool mine = (uint32_t)lane < n;
+		const bool mine = (uint32_t)li < n;
 		pgx_hit h;
+		h.subject = h.score = h.qstart = h.qend = h.sstart = h.send = h.mismatch = h.read = 0;
 		if (mine) {
-			h = src[lane];
-			sw->a.subj[lane] = h.subject;
-			sw->a.score[lane] = h.score;
+			h = src[li];
+			sw->a.subj[slot0 + li] = h.subject;
+			sw->a.score[slot0 + li] = h.score;
 		}
-		// the read's RDP codes, wave-uniform, in registers (slots past the end match nothing)
+		// the read's RDP codes (slots past the end match nothing)
 		uint32_t rcode[kRdpRegs], rdp0 = 0, rdp1 = 0;
-		if (do_consensus) {
-			rdp0 = __builtin_amdgcn_readfirstlane(cv.rdp_off[r]);
-			rdp1 = __builtin_amdgcn_readfirstlane(cv.rdp_off[r + 1]);
+		if (do_consensus && n) {
+			rdp0 = cv.rdp_off[r];
+			rdp1 = cv.rdp_off[r + 1];
 #pragma unroll
 			for (int b = 0; b < kRdpRegs; b++)
 				rcode[b] = rdp0 + b < rdp1 ? cv.rdp_code[rdp0 + b] : 0xFFFFFFFEu;
+		} else {
+#pragma unroll
+			for (int b = 0; b < kRdpRegs; b++)
+				rcode[b] = 0xFFFFFFFEu;
 		}
 		lds_fence();
 		// best score of the hit's subject
-		int best = 0;
+		int best = h.score;
 		if (mine) {
-			best = h.score;
 			for (uint32_t j = 0; j < n; j++)
-				if (sw->a.subj[j] == h.subject && sw->a.score[j] > best)
-					best = sw->a.score[j];
+				if (sw->a.subj[slot0 + j] == h.subject && sw->a.score[slot0 + j] > best)
+					best = sw->a.score[slot0 + j];
 		}
-		SortKey kx = make_key(h, best);
+		const SortKey kx = make_key(h, best);
+		lds_fence();
 		if (mine) {
-			sw->a.k1[lane] = kx.k1;
-			sw->a.k2[lane] = kx.k2;
-			sw->a.k3[lane] = kx.k3;
+			sw->a.k1[slot0 + li] = kx.k1;
+			sw->a.k2[slot0 + li] = kx.k2;
+			sw->a.k3[slot0 + li] = kx.k3;
 		}
 		lds_fence();
 		// rank = number of hits that precede this one
@@ -959,10 +974,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		if (mine) {
 			for (uint32_t j = 0; j < n; j++) {
 				SortKey kj;
-				kj.k1 = sw->a.k1[j];
-				kj.k2 = sw->a.k2[j];
-				kj.k3 = sw->a.k3[j];
-				rank += key_less(kj, kx) || (!key_less(kx, kj) && j < (uint32_t)lane);
+				kj.k1 = sw->a.k1[slot0 + j];
+				kj.k2 = sw->a.k2[slot0 + j];
+				kj.k3 = sw->a.k3[slot0 + j];
+				rank += key_less(kj, kx) || (!key_less(kx, kj) && j < (uint32_t)li);
 			}
 			hits[o + rank] = h;
 		}
@@ -975,13 +990,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
 		if (mine) {
-			sw->b.rm[rank] = rmv;
-			sw->b.sim[rank] = sim;
-			sw->b.krm[rank] = dec_str_key(rmv);
-			sw->b.kcnt[rank] = dec_str_key(ntok);
+			sw->b.rm[slot0 + rank] = rmv;
+			sw->b.sim[slot0 + rank] = sim;
+			sw->b.krm[slot0 + rank] = dec_str_key(rmv);
+			sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
 		}
 		lds_fence();
-		if (lane == 0) {
+		if (li == 0 && n) {
 			// Consensus:186-204, strictly in table order
 			pgx_consensus_rec rec;
 			rec.hit = -1;
@@ -992,7 +1007,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 				ArgmaxState am;
 				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
 				for (uint32_t k = 0; k < n; k++)
-					am.step_keys((int32_t)(o + k), sw->b.rm[k], sw->b.krm[k], sw->b.kcnt[k], sw->b.sim[k]);
+					am.step_keys((int32_t)(o + k), sw->b.rm[slot0 + k], sw->b.krm[slot0 + k], sw->b.kcnt[slot0 + k],
+						     sw->b.sim[slot0 + k]);
 				rec.hit = am.win;
 				rec.matches = (int32_t)am.maxrm;
 			}
@@ -1164,7 +1180,7 @@ struct EventTimer {
 struct Workspace {
 	DevBuf<unsigned long long> counters;
 	DevBuf<pgx_hit> scratch, ovf;
-	DevBuf<uint32_t> partial, cursor, big_list, big_count, read_start;
+	DevBuf<uint32_t> partial, cursor, big_list, big_count, read_start, mid_list, mid_count;
 	DevBuf<pgx_consensus_rec> recs;
 	pgx_hits hits; // used when the caller does not keep the hit table
 	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0;
@@ -1278,9 +1294,20 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_TRY(big_count.ensure(1));
 	PGX_HIP(hipMemsetAsync(big_count.data(), 0, sizeof(uint32_t), 0));
 	const ConsView cv = cons_view(db, rdp);
-	hipLaunchKernelGGL(k_sort_consensus, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
-			   read_start.data(), out->d_read_off.data(), out->d_read_cnt.data(), (uint32_t)n, cv, rdp ? 1 : 0, rd->max_len <= 65535 ? 1 : 0, d_recs,
-			   big_list.data(), big_count.data());
+	// two reads per wavefront first; reads with 33..64 hits go through `mid_list` to the one-read-per-wave launch,
+	// which passes reads with more than 64 hits on to `big_list`
+	DevBuf<uint32_t> &mid_list = g_ws.mid_list, &mid_count = g_ws.mid_count;
+	PGX_TRY(mid_list.ensure(n));
+	PGX_TRY(mid_count.ensure(1));
+	PGX_HIP(hipMemsetAsync(mid_count.data(), 0, sizeof(uint32_t), 0));
+	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
+	const int grid2 = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
+	hipLaunchKernelGGL(k_sort_consensus<32>, dim3(grid2), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
+			   read_start.data(), out->d_read_off.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv,
+			   rdp ? 1 : 0, lds_ok, d_recs, mid_list.data(), mid_count.data());
+	hipLaunchKernelGGL(k_sort_consensus<64>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
+			   read_start.data(), out->d_read_off.data(), (uint32_t)n, mid_list.data(), mid_count.data(), cv, rdp ? 1 : 0,
+			   lds_ok, d_recs, big_list.data(), big_count.data());
 	PGX_HIP(hipGetLastError());
 	uint32_t n_big = 0;
 	PGX_TRY(big_count.download(&n_big, 1));
