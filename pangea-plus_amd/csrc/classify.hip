@@ -243,12 +243,18 @@ constexpr int kQueue = 64 * (kDeal + 1); // candidate queue per wave (filled 64*
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
+
 struct WaveLds {
-	pgx_hit hit[kStage];
+	// one read per wave: kStage full records.  Two reads per wave (reads of <= 192 bases): kStage 16-byte
+	// records per read in the same bytes: subject, sstart, qstart | qend << 16 | minus << 31, score | mismatch << 16
+	union {
+		pgx_hit hit[kStage];
+		uint4 chit[2 * kStage];
+	};
 	// queued candidates: posting, strand << 31 | tested << 30 | qpos, and the subject found while filtering
 	uint32_t qp[kQueue], qmeta[kQueue], qsubj[kQueue], qs0[kQueue], qs1[kQueue];
-	unsigned int n;                      // staged hits
-	unsigned int direct;                 // hits that found the stage full and went straight to the overflow table
+	unsigned int n[2];                   // staged hits per read slot
+	unsigned int direct[2];              // hits that found the stage full and went straight to the overflow table
 };
 
 struct OutView {
@@ -261,13 +267,40 @@ struct OutView {
 constexpr unsigned int kChunk = 2048; // main-table slots a wave reserves with one atomic (a single hot counter
 				      // sustains only ~90 M atomics/s: one per read would cost more than the search)
 
-__device__ __forceinline__ void emit_hit(WaveLds *st, const OutView &ov, const pgx_hit &h)
+__device__ __forceinline__ uint4 pack_hit(const pgx_hit &h)
 {
-	unsigned int slot = atomicAdd(&st->n, 1u);
+	const uint32_t minus = h.sstart > h.send;
+	return make_uint4((uint32_t)h.subject, (uint32_t)h.sstart, (uint32_t)h.qstart | ((uint32_t)h.qend << 16) | (minus << 31),
+			  (uint32_t)h.score | ((uint32_t)h.mismatch << 16));
+}
+
+__device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
+{
+	pgx_hit h;
+	h.read = (int32_t)read;
+	h.subject = (int32_t)c.x;
+	h.sstart = (int32_t)c.y;
+	h.qstart = (int32_t)(c.z & 0xFFFFu);
+	h.qend = (int32_t)((c.z >> 16) & 0x7FFFu);
+	const int span = h.qend - h.qstart;
+	h.send = (c.z >> 31) ? h.sstart - span : h.sstart + span;
+	h.score = (int32_t)(c.w & 0xFFFFu);
+	h.mismatch = (int32_t)(c.w >> 16);
+	return h;
+}
+
+// PACKED: two reads share the wavefront, read slot `rs` stages 16-byte records
+template <bool PACKED>
+__device__ __forceinline__ void emit_hit(WaveLds *st, int rs, const OutView &ov, const pgx_hit &h)
+{
+	unsigned int slot = atomicAdd(&st->n[rs], 1u);
 	if (slot < (unsigned)kStage) {
-		st->hit[slot] = h;
+		if (PACKED)
+			st->chit[rs * kStage + slot] = pack_hit(h);
+		else
+			st->hit[slot] = h;
 	} else {
-		atomicAdd(&st->direct, 1u);
+		atomicAdd(&st->direct[rs], 1u);
 		unsigned long long g = atomicAdd(&ov.counters[4], 1ull);
 		if (g < ov.ovf_cap)
 			ov.ovf[g] = h;
@@ -276,10 +309,10 @@ __device__ __forceinline__ void emit_hit(WaveLds *st, const OutView &ov, const p
 
 // One candidate = one (strand, probe position, posting).  `tested` says the index already proved that
 // this probe is the left-most one of its exact run (test 1 below).
-template <bool AMB, class Mask>
+template <bool AMB, class Mask, class Emit>
 __device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read,
 						   int strand, int qp, uint32_t p, bool tested, uint32_t s, uint32_t s_start,
-						   uint32_t s_end, WaveLds *st, const OutView &ov, unsigned long long &n_runs)
+						   uint32_t s_end, Emit &emit, unsigned long long &n_runs)
 {
 	if (p + (uint32_t)kSeedK > s_end)
 		return; // seed straddles two subjects
@@ -396,7 +429,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				h.send = (int32_t)sl;
 			}
 			if (db.dbg_stop != 7)
-				emit_hit(st, ov, h);
+				emit(h);
 			covered = br + 1;
 		}
 		if constexpr (Mask::kHasWindows)
@@ -427,31 +460,71 @@ __device__ __forceinline__ void lds_fence()
 //               so the expensive diagonal work always runs with full lanes
 //   output      hits are staged in LDS and leave with ONE atomic per read, contiguously (read_start/read_cnt);
 //               a read that overflows the stage is marked fragmented and goes through the overflow table
+// RPW = reads per wavefront.  Reads of <= 192 bases need at most 28 probes, so two of them share a wavefront:
+// lanes 0-31 probe the first, lanes 32-63 the second, their postings are dealt together and their candidates
+// drained together (160 candidates fill 64-lane drains far better than 80), each read staging its hits in
+// its own half of the stage.  Longer reads keep the wavefront to themselves.
 template <bool AMB, bool DENSE>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
 								      uint32_t *__restrict__ read_cnt,
 								      uint32_t *__restrict__ read_start)
 {
+	constexpr int RPW = DENSE ? 2 : 1;
+	constexpr int LPR = 64 / RPW;                     // probe lanes per read
+	constexpr unsigned int SLOT_CAP = kStage;         // staged hits per read (16-byte records when two reads share)
 	__shared__ WaveLds s_lds[kWavesPerBlock];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int my_rs = lane / LPR, my_li = lane % LPR; // read slot / probe lane of this lane
 	WaveLds *st = &s_lds[wave];
 	unsigned long long n_probe = 0, n_post = 0, n_runs = 0, n_main = 0, n_surv = 0;
 	unsigned long long chunk_base = 0;
 	unsigned int chunk_used = kChunk; // forces a reservation at the first flush
 	const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
-	for (uint32_t r = blockIdx.x * kWavesPerBlock + wave; r < rd.n; r += gridDim.x * kWavesPerBlock) {
-		const int L = (int)rd.len[r];
-		const uint32_t w0 = rd.woff[r];
+	for (uint32_t rbase = (blockIdx.x * kWavesPerBlock + wave) * RPW; rbase < rd.n; rbase += gridDim.x * kWavesPerBlock * RPW) {
+		// wave-uniform description of the (up to) two reads
+		const uint32_t rA = rbase, rB = rbase + 1;
+		const bool hasB = RPW == 2 && rB < rd.n;
+		const int LA = (int)rd.len[rA], LB = hasB ? (int)rd.len[rB] : 0;
+		const uint32_t wA = rd.woff[rA], wB = hasB ? rd.woff[rB] : 0u;
+		// this lane's own read (for the probe phase)
+		const int L = my_rs ? LB : LA;
+		const uint32_t w0 = my_rs ? wB : wA;
 		const int nps = L >= kSeedK ? (L - kSeedK) / kProbeStride + 1 : 0;
-		const int P = 2 * nps;
-		unsigned int emitted = 0, q_n = 0;
-		bool frag = false;
+		const int P = 2 * nps; // probes of this lane's read
+		// longest probe list among the reads of the wave (one chunk of LPR lanes per round)
+		const int PA = LA >= kSeedK ? 2 * ((LA - kSeedK) / kProbeStride + 1) : 0;
+		const int PB = LB >= kSeedK ? 2 * ((LB - kSeedK) / kProbeStride + 1) : 0;
+		const int Pmax = PA > PB ? PA : PB;
+		unsigned int emitted[2] = { 0, 0 }, q_n = 0;
+		bool frag[2] = { false, false };
 		if (lane == 0) {
-			st->n = 0;
-			st->direct = 0;
+			st->n[0] = st->n[1] = 0;
+			st->direct[0] = st->direct[1] = 0;
 		}
 		lds_fence();
+
+		// spill one read's staged hits to the overflow table in the middle of the work: it becomes fragmented
+		auto spill = [&](int rs) {
+			unsigned int n = st->n[rs];
+			if (n > SLOT_CAP)
+				n = SLOT_CAP;
+			unsigned long long base = 0;
+			if (lane == 0)
+				base = atomicAdd(&ov.counters[4], (unsigned long long)n);
+			base = __shfl(base, 0);
+			for (unsigned int i = lane; i < n; i += 64)
+				if (base + i < ov.ovf_cap)
+					ov.ovf[base + i] = RPW == 2 ? unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA) : st->hit[i];
+			if (rs)
+				emitted[1] += n, frag[1] = true;
+			else
+				emitted[0] += n, frag[0] = true;
+			lds_fence();
+			if (lane == 0)
+				st->n[rs] = 0;
+			lds_fence();
+		};
 
 		auto drain = [&](unsigned int cnt) {
 			// the last `cnt` queue entries, one per lane
@@ -459,46 +532,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 			if ((unsigned)lane < cnt && db.dbg_stop != 3) {
 				const uint32_t p = st->qp[q_n + lane], meta = st->qmeta[q_n + lane];
 				const uint32_t sj = st->qsubj[q_n + lane], s0 = st->qs0[q_n + lane], s1 = st->qs1[q_n + lane];
-				const int strand = (int)(meta >> 31), qp = (int)(meta & 0x3FFFFFFFu);
+				const int strand = (int)(meta >> 31), rs = (int)((meta >> 29) & 1), qp = (int)(meta & 0x1FFFFFFFu);
 				const bool tested = (meta >> 30) & 1;
-				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
+				const uint32_t cw0 = rs ? wB : wA, cr = rs ? rB : rA;
+				const int cL = rs ? LB : LA;
+				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + cw0;
 				const uint64_t *ra = nullptr;
 				if (AMB) {
 					const uint64_t *a = strand ? rd.rc_amb : rd.fwd_amb;
-					ra = a ? a + w0 : nullptr;
+					ra = a ? a + cw0 : nullptr;
 				}
+				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh); };
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, sj, s0, s1, st, ov, n_runs);
+					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, sj, s0, s1, emit, n_runs);
 				else
-					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, L, r, strand, qp, p, tested, sj, s0, s1, st, ov, n_runs);
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, sj, s0, s1, emit, n_runs);
 			}
 			lds_fence();
-			// a stage more than half full in the middle of a read: the read becomes fragmented
-			unsigned int n = st->n;
-			if (n > (unsigned)kStage / 2) {
-				if (n > (unsigned)kStage)
-					n = kStage;
-				unsigned long long base = 0;
-				if (lane == 0)
-					base = atomicAdd(&ov.counters[4], (unsigned long long)n);
-				base = __shfl(base, 0);
-				for (unsigned int i = lane; i < n; i += 64)
-					if (base + i < ov.ovf_cap)
-						ov.ovf[base + i] = st->hit[i];
-				emitted += n;
-				frag = true;
-				lds_fence();
-				if (lane == 0)
-					st->n = 0;
-				lds_fence();
-			}
+			// a read's stage more than half full in the middle of the work: the read becomes fragmented
+			if (st->n[0] > SLOT_CAP / 2)
+				spill(0);
+			if (RPW == 2 && st->n[1] > SLOT_CAP / 2)
+				spill(1);
 		};
 
-		for (int pbase = 0; pbase < P; pbase += 64) {
-			const int pid = pbase + lane;
+		for (int pbase = 0; pbase < Pmax; pbase += LPR) {
+			const int pid = pbase + my_li;
 			uint32_t cnt = 0, lo = 0;
 			int strand = 0, qpos = 0;
-			if (pid < P) {
+			if (pid < P && (my_rs == 0 || hasB)) {
 				strand = pid >= nps;
 				qpos = (pid - strand * nps) * kProbeStride;
 				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
@@ -513,6 +575,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 					lo = db.bucket_off[b];
 					cnt = db.bucket_off[(uint64_t)b + 1] - lo;
 				}
+				n_probe++;
 			}
 			// wave prefix sum of the posting counts
 			uint32_t incl = cnt;
@@ -524,7 +587,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 			}
 			const uint32_t excl = incl - cnt;
 			const uint32_t T = __shfl(incl, 63);
-			n_probe += (pid < P);
 			n_post += cnt;
 			if (db.dbg_stop == 1)
 				continue;
@@ -532,7 +594,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 				// kDeal postings per lane, every load of a stage issued before the first use
 				bool active[kDeal], tested[kDeal], keep[kDeal];
 				uint32_t pidx[kDeal], p[kDeal], sj[kDeal], s0[kDeal], s1[kDeal];
-				int o_strand[kDeal], o_qpos[kDeal];
+				int o_strand[kDeal], o_qpos[kDeal], o_rs[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					const uint32_t item = it + 64 * u + lane;
@@ -550,6 +612,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 					pidx[u] = __shfl(lo, o) + (key - __shfl(excl, o));
 					o_strand[u] = __shfl(strand, o);
 					o_qpos[u] = __shfl(qpos, o);
+					o_rs[u] = o / LPR;
 				}
 				uint32_t raw[kDeal];
 #pragma unroll
@@ -570,7 +633,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 						if (!AMB && !(raw[u] >> 31) && o_qpos[u] >= kProbeStride) {
 							tested[u] = true;
 							left[u] = kmer16(db.words, (int64_t)p[u] - kProbeStride);
-							want[u] = kmer16((o_strand[u] ? rd.rc : rd.fwd) + w0, o_qpos[u] - kProbeStride);
+							want[u] = kmer16((o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA), o_qpos[u] - kProbeStride);
 						}
 					}
 				}
@@ -603,7 +666,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 					if (keep[u]) {
 						const unsigned int slot = q_n + (unsigned)__popcll(km & lt_mask);
 						st->qp[slot] = p[u];
-						st->qmeta[slot] = ((uint32_t)o_strand[u] << 31) | ((uint32_t)tested[u] << 30) | (uint32_t)o_qpos[u];
+						st->qmeta[slot] = ((uint32_t)o_strand[u] << 31) | ((uint32_t)tested[u] << 30) | ((uint32_t)o_rs[u] << 29) |
+								  (uint32_t)o_qpos[u];
 						st->qsubj[slot] = sj[u];
 						st->qs0[slot] = s0[u];
 						st->qs1[slot] = s1[u];
@@ -619,43 +683,51 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_seed_extend(DbView db, 
 		if (q_n)
 			drain(q_n);
 		lds_fence();
-		unsigned int n = st->n;
-		if (n > (unsigned)kStage)
-			n = kStage;
-		if (st->direct)
-			frag = true;
-		uint32_t start = kFragmented;
-		if (n) {
-			unsigned long long base = 0;
-			if (frag) {
-				if (lane == 0)
-					base = atomicAdd(&ov.counters[4], (unsigned long long)n);
-				base = __shfl(base, 0);
-			} else {
-				// sub-allocate from the wave's chunk of the main table
-				if (chunk_used + n > kChunk) {
+		// close the reads: staged hits leave contiguously into the wave's chunk of the hit table
+#pragma unroll
+		for (int rs = 0; rs < RPW; rs++) {
+			if (rs == 1 && !hasB)
+				break;
+			unsigned int n = st->n[rs];
+			if (n > SLOT_CAP)
+				n = SLOT_CAP;
+			bool fr = rs ? frag[1] : frag[0];
+			if (st->direct[rs])
+				fr = true;
+			uint32_t start = kFragmented;
+			unsigned int em = rs ? emitted[1] : emitted[0];
+			if (n) {
+				unsigned long long base = 0;
+				if (fr) {
 					if (lane == 0)
-						chunk_base = atomicAdd(&ov.counters[0], (unsigned long long)kChunk);
-					chunk_base = __shfl(chunk_base, 0);
-					chunk_used = 0;
+						base = atomicAdd(&ov.counters[4], (unsigned long long)n);
+					base = __shfl(base, 0);
+				} else {
+					// sub-allocate from the wave's chunk of the main table
+					if (chunk_used + n > kChunk) {
+						if (lane == 0)
+							chunk_base = atomicAdd(&ov.counters[0], (unsigned long long)kChunk);
+						chunk_base = __shfl(chunk_base, 0);
+						chunk_used = 0;
+					}
+					base = chunk_base + chunk_used;
+					chunk_used += n;
+					n_main += lane == 0 ? n : 0;
 				}
-				base = chunk_base + chunk_used;
-				chunk_used += n;
-				n_main += lane == 0 ? n : 0;
+				pgx_hit *dst = fr ? ov.ovf : ov.main;
+				const unsigned long long dcap = fr ? ov.ovf_cap : ov.main_cap;
+				for (unsigned int i = lane; i < n; i += 64)
+					if (base + i < dcap)
+						dst[base + i] = RPW == 2 ? unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA) : st->hit[i];
+				em += n;
+				if (!fr)
+					start = (uint32_t)base;
 			}
-			pgx_hit *dst = frag ? ov.ovf : ov.main;
-			const unsigned long long dcap = frag ? ov.ovf_cap : ov.main_cap;
-			for (unsigned int i = lane; i < n; i += 64)
-				if (base + i < dcap)
-					dst[base + i] = st->hit[i];
-			emitted += n;
-			if (!frag)
-				start = (uint32_t)base;
-		}
-		emitted += st->direct;
-		if (lane == 0) {
-			read_cnt[r] = emitted;
-			read_start[r] = start;
+			em += st->direct[rs];
+			if (lane == 0) {
+				read_cnt[rs ? rB : rA] = em;
+				read_start[rs ? rB : rA] = start;
+			}
 		}
 		lds_fence();
 	}
@@ -1210,6 +1282,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	const ReadsView rv = reads_view(rd);
 	const bool amb = db->has_amb || rd->has_amb;
 	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
+	const int grid_seed = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
 	EventTimer total, t;
 	total.start();
 
@@ -1235,7 +1308,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		ov.ovf_cap = ovf_cap;
 		ov.counters = counters.data();
 		t.start();
-		const dim3 g(grid), b(64 * kWavesPerBlock);
+		const dim3 g(dense ? grid_seed : grid), b(64 * kWavesPerBlock);
 		if (amb && dense)
 			hipLaunchKernelGGL((k_seed_extend<true, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
 		else if (amb)
