@@ -190,6 +190,66 @@ template <bool AMB> struct DenseMask {
 		int r = b2 ? 191 - __clzll((long long)b2) : (b1 ? 127 - __clzll((long long)b1) : (b0 ? 63 - __clzll((long long)b0) : -1));
 		return r >= lo ? r : lo - 1;
 	}
+	// Cursors over the flags for the X-drop walks: the current 64-flag word is consumed bit by bit
+	// (one count-zeros and one clear per mismatch); a new word is picked only when it runs empty.
+	struct Fwd {
+		uint64_t w;
+		int wi;
+	};
+	// flagged positions > k, ascending (k in [-1, 191])
+	__device__ __forceinline__ Fwd fwd_from(int k) const
+	{
+		const int pos = k + 1;
+		Fwd c;
+		c.wi = pos >> 6;
+		const uint64_t word = c.wi == 0 ? m0 : (c.wi == 1 ? m1 : (c.wi == 2 ? m2 : 0ull));
+		c.w = word & (~0ull << (pos & 63));
+		return c;
+	}
+	__device__ __forceinline__ int fwd_next(Fwd &c) const
+	{
+		while (!c.w) {
+			c.wi++;
+			if (c.wi >= 3)
+				return hi;
+			c.w = c.wi == 1 ? m1 : m2;
+		}
+		const int r = c.wi * 64 + __ffsll((unsigned long long)c.w) - 1;
+		c.w &= c.w - 1;
+		return r < hi ? r : hi;
+	}
+	struct Bwd {
+		uint64_t w;
+		int wi;
+	};
+	// flagged positions < k, descending (k in [0, 192])
+	__device__ __forceinline__ Bwd bwd_from(int k) const
+	{
+		Bwd c;
+		if (k <= 0) {
+			c.w = 0;
+			c.wi = 0;
+			return c;
+		}
+		const int q = k - 1, b = q & 63;
+		c.wi = q >> 6;
+		const uint64_t word = c.wi == 0 ? m0 : (c.wi == 1 ? m1 : m2);
+		c.w = word & (b == 63 ? ~0ull : ((2ull << b) - 1));
+		return c;
+	}
+	__device__ __forceinline__ int bwd_next(Bwd &c) const
+	{
+		while (!c.w) {
+			if (c.wi == 0)
+				return lo - 1;
+			c.wi--;
+			c.w = c.wi == 0 ? m0 : m1;
+		}
+		const int b = 63 - __clzll((long long)c.w);
+		c.w ^= 1ull << b;
+		const int r = c.wi * 64 + b;
+		return r >= lo ? r : lo - 1;
+	}
 };
 
 template <bool AMB> struct LazyMask {
@@ -235,6 +295,16 @@ template <bool AMB> struct LazyMask {
 		int r = 32 * w + ((63 - __clzll((long long)m)) >> 1);
 		return r >= lo ? r : lo - 1;
 	}
+	struct Fwd {
+		int k;
+	};
+	__device__ __forceinline__ Fwd fwd_from(int k) const { return Fwd{ k }; }
+	__device__ __forceinline__ int fwd_next(Fwd &c) const { return c.k = first_ge(c.k + 1); }
+	struct Bwd {
+		int k;
+	};
+	__device__ __forceinline__ Bwd bwd_from(int k) const { return Bwd{ k }; }
+	__device__ __forceinline__ int bwd_next(Bwd &c) const { return c.k = last_lt(c.k); }
 };
 
 constexpr int kStage = 128; // hits staged in LDS per wave between flushes
@@ -373,12 +443,13 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		if (len >= kWord && pos >= covered) {
 			int best = 0, cur = 0, bl = pos, nmm = 0, mm_best = 0;
 			int k = pos - 1; // a flagged position, or lo-1
+			typename Mask::Bwd cl = M.bwd_from(k);
 			while (k >= D.lo) {
 				cur -= 2;
 				nmm++;
 				if (best - cur > kXdrop)
 					break;
-				int p2 = M.last_lt(k);
+				int p2 = M.bwd_next(cl);
 				int n = k - 1 - p2;
 				if (n > 0) {
 					cur += n;
@@ -394,12 +465,13 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 			cur = 0;
 			nmm = 0;
 			k = e; // a flagged position, or hi
+			typename Mask::Fwd cr = M.fwd_from(k);
 			while (k < D.hi) {
 				cur -= 2;
 				nmm++;
 				if (bestr - cur > kXdrop)
 					break;
-				int n2 = M.first_ge(k + 1);
+				int n2 = M.fwd_next(cr);
 				int n = n2 - (k + 1);
 				if (n > 0) {
 					cur += n;
