@@ -690,30 +690,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 #pragma unroll
 				for (int u = 0; u < kDeal; u++)
 					raw[u] = active[u] ? db.postings[pidx[u]] : 0u;
-				// stage 2: block table entry of the posting and, unless the posting sits within 13 bases of a
-				// sequence start (bit 31), the database 16-mer 13 bases to its left
-				uint32_t left[kDeal], want[kDeal];
+				// stage 2: block table entry of the posting, and the 13 database bases left and 12 right of
+				// the 16-mer against the read's (two 64-bit windows each; the read's come from L1)
+				uint64_t xl[kDeal], xr[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					p[u] = raw[u] & 0x7FFFFFFFu;
 					keep[u] = active[u];
 					tested[u] = false;
-					left[u] = want[u] = 0;
+					xl[u] = xr[u] = 0;
 					sj[u] = 0;
 					if (active[u]) {
 						sj[u] = db.blk_subj[p[u] >> kBlkShift];
-						if (!AMB && !(raw[u] >> 31) && o_qpos[u] >= kProbeStride) {
-							tested[u] = true;
-							left[u] = kmer16(db.words, (int64_t)p[u] - kProbeStride);
-							want[u] = kmer16((o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA), o_qpos[u] - kProbeStride);
+						if (!AMB) {
+							const uint64_t *rwp = (o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA);
+							if (o_qpos[u] >= kProbeStride) {
+								// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
+								tested[u] = !(raw[u] >> 31);
+								xl[u] = window64(db.words, (int64_t)p[u] - kProbeStride) ^
+									window64(rwp, o_qpos[u] - kProbeStride);
+							}
+							xr[u] = window64(db.words, (int64_t)p[u] + kSeedK) ^ window64(rwp, o_qpos[u] + kSeedK);
 						}
 					}
 				}
-				// stage 3: an equal 16-mer to the left means the previous probe reports this run: drop
+				// stage 3: la / ra = matching bases immediately left / right of the 16-mer (capped at 13 / 12,
+				// and by the read's ends).  la == 13: the previous probe reports this run: drop.
+				// la + 16 + ra < 28: the exact run around the 16-mer is shorter than a word: drop.
+				// (Subject boundaries are ignored here, so this only ever keeps too much; the exact tests
+				// follow on the diagonal's flags.)
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
-					if (tested[u] && left[u] == want[u])
-						keep[u] = false;
+					if (!AMB && keep[u]) {
+						const uint32_t ml = (uint32_t)((xl[u] | (xl[u] >> 1)) & kEven) & 0x03FFFFFFu;
+						const uint32_t mr = (uint32_t)((xr[u] | (xr[u] >> 1)) & kEven) & 0x00FFFFFFu;
+						int la = o_qpos[u] >= kProbeStride ? (ml ? 12 - ((31 - __clz((int)ml)) >> 1) : kProbeStride) : 0;
+						int ra = mr ? (__ffs((int)mr) - 1) >> 1 : kWord - kSeedK;
+						if (tested[u] && la == kProbeStride)
+							keep[u] = false;
+						const int room = (o_rs[u] ? LB : LA) - o_qpos[u] - kSeedK;
+						ra = ra < room ? ra : room;
+						if (la + ra < kWord - kSeedK)
+							keep[u] = false;
+					}
 					s0[u] = s1[u] = 0;
 					if (keep[u]) {
 						uint32_t a = db.seq_off[sj[u]], b = db.seq_off[sj[u] + 1];
