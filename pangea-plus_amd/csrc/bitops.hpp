@@ -34,6 +34,18 @@ __device__ __forceinline__ uint32_t kmer16(const uint64_t *words, int64_t pos)
 	return (uint32_t)window64(words, pos);
 }
 
+// 16 bases starting at base `pos` (pos >= -32): ONE 8-byte load at 4-byte alignment plus one funnel shift
+// (64 - 2*(pos & 15) >= 34 valid bits, so the low 32 are always whole)
+struct __attribute__((packed, aligned(4))) U64Align4 {
+	uint64_t v;
+};
+__device__ __forceinline__ uint32_t window16(const uint64_t *words, int64_t pos)
+{
+	const uint32_t *d = reinterpret_cast<const uint32_t *>(words);
+	const uint64_t v = reinterpret_cast<const U64Align4 *>(d + (pos >> 4))->v;
+	return (uint32_t)(v >> ((int)(pos & 15) * 2));
+}
+
 __host__ __device__ __forceinline__ uint32_t seed_bucket(uint32_t kmer, int bits)
 {
 	return bits >= 32 ? kmer : (uint32_t)((kmer * 0x9E3779B1u) >> (32 - bits));

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						ok = false;
 				}
 				if (ok) {
-					uint32_t b = seed_bucket(kmer16(rw, qpos), db.bits);
+					uint32_t b = seed_bucket(window16(rw, qpos), db.bits);
 					lo = db.bucket_off[b];
 					cnt = db.bucket_off[(uint64_t)b + 1] - lo;
 				}
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				for (int u = 0; u < kDeal; u++)
 					raw[u] = active[u] ? db.postings[pidx[u]] : 0u;
 				// stage 2: block table entry of the posting, and the 13 database bases left and 12 right of
-				// the 16-mer against the read's (two 64-bit windows each; the read's come from L1)
-				uint64_t xl[kDeal], xr[kDeal];
+				// the 16-mer against the read's (one 8-byte load each; the read's come from L1)
+				uint32_t xl[kDeal], xr[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					p[u] = raw[u] & 0x7FFFFFFFu;
@@ -707,10 +707,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 							if (o_qpos[u] >= kProbeStride) {
 								// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
 								tested[u] = !(raw[u] >> 31);
-								xl[u] = window64(db.words, (int64_t)p[u] - kProbeStride) ^
-									window64(rwp, o_qpos[u] - kProbeStride);
+								xl[u] = window16(db.words, (int64_t)p[u] - kProbeStride) ^
+									window16(rwp, o_qpos[u] - kProbeStride);
 							}
-							xr[u] = window64(db.words, (int64_t)p[u] + kSeedK) ^ window64(rwp, o_qpos[u] + kSeedK);
+							xr[u] = window16(db.words, (int64_t)p[u] + kSeedK) ^ window16(rwp, o_qpos[u] + kSeedK);
 						}
 					}
 				}
@@ -722,8 +722,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					if (!AMB && keep[u]) {
-						const uint32_t ml = (uint32_t)((xl[u] | (xl[u] >> 1)) & kEven) & 0x03FFFFFFu;
-						const uint32_t mr = (uint32_t)((xr[u] | (xr[u] >> 1)) & kEven) & 0x00FFFFFFu;
+						const uint32_t ml = (xl[u] | (xl[u] >> 1)) & 0x01555555u; // bases 0..12
+						const uint32_t mr = (xr[u] | (xr[u] >> 1)) & 0x00555555u; // bases 0..11
 						int la = o_qpos[u] >= kProbeStride ? (ml ? 12 - ((31 - __clz((int)ml)) >> 1) : kProbeStride) : 0;
 						int ra = mr ? (__ffs((int)mr) - 1) >> 1 : kWord - kSeedK;
 						if (tested[u] && la == kProbeStride)
