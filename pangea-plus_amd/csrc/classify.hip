@@ -963,6 +963,7 @@ struct ConsView {
 	const uint8_t *rdp_present;
 	const uint32_t *subj_pairs; // 16 words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
 	const uint32_t *rdp_code;   // name << 3 | rank + 1 per RDP triplet
+	int dbg;                    // profiling aid (PGX_SORT_STOP): truncate k_sort_consensus after a stage
 };
 
 // string-order rank of the hit's pident text
@@ -1013,29 +1014,23 @@ __device__ __forceinline__ uint32_t hit_rank_matches(const ConsView &cv, uint32_
 	return rank_matches(cv.subj_tok + t0, nt, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
 }
 
+constexpr uint32_t kNoRead = 0xFFFFFFFFu; // hole in a chunked read list
 constexpr int kSortCap = 64; // hits of one read ordered by its wave: one hit per lane
 
-// S5 order as three integers compared lexicographically (reads up to 65 535 bases; longer reads take the
-// field-by-field comparison of the big-read path)
+// S5 order as two integers compared lexicographically (reads up to 65 535 bases; longer reads take the
+// field-by-field comparison of the big-read path).  `send` needs one bit: with equal qstart, qend and sstart
+// the minus-strand hit (send = sstart - span) precedes the plus-strand one (send = sstart + span);
+// sstart < 2^31 because database positions are.
 struct SortKey {
 	uint64_t k1, k2;
-	uint32_t k3;
 };
 __device__ __forceinline__ SortKey make_key(const pgx_hit &h, int best)
 {
 	SortKey k;
 	k.k1 = ((uint64_t)(0xFFFF - best) << 48) | ((uint64_t)(uint32_t)h.subject << 16) | (uint64_t)(0xFFFF - h.score);
-	k.k2 = ((uint64_t)(uint32_t)h.qstart << 48) | ((uint64_t)(uint32_t)h.qend << 32) | (uint64_t)(uint32_t)h.sstart;
-	k.k3 = (uint32_t)h.send;
+	k.k2 = ((uint64_t)(uint32_t)h.qstart << 48) | ((uint64_t)(uint32_t)h.qend << 32) |
+	       (uint64_t)(((uint32_t)h.sstart << 1) | (h.send > h.sstart ? 1u : 0u));
 	return k;
-}
-__device__ __forceinline__ bool key_less(const SortKey &a, const SortKey &b)
-{
-	if (a.k1 != b.k1)
-		return a.k1 < b.k1;
-	if (a.k2 != b.k2)
-		return a.k2 < b.k2;
-	return a.k3 < b.k3;
 }
 
 // LDS of one wave.  Phase A holds (subject, score) pairs then the sort keys; phase B (after every lane has
@@ -1045,7 +1040,6 @@ struct SortWave {
 	union {
 		struct {
 			uint64_t k1[kSortCap], k2[kSortCap];
-			uint32_t k3[kSortCap];
 			int subj[kSortCap], score[kSortCap];
 		} a;
 		struct {
@@ -1076,22 +1070,48 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 	const int lane = threadIdx.x & 63;
 	const int g = lane / G, li = lane % G, slot0 = g * G;
 	const uint32_t total = list ? *n_list_ptr : n_reads;
+	uint32_t chunk_base = 0, chunk_used = 64; // this wave's chunk of next_list (G == 32)
 	for (uint32_t base = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW; base < total;
 	     base += gridDim.x * kWavesPerBlock * RPW) {
 		const uint32_t idx = base + (uint32_t)g;
-		const bool valid = idx < total;
-		const uint32_t r = valid ? (list ? list[idx] : idx) : 0u;
+		bool valid = idx < total;
+		uint32_t r = valid ? (list ? list[idx] : idx) : 0u;
+		if (r == kNoRead) { // unused slot of a chunked list
+			valid = false;
+			r = 0;
+		}
 		const uint32_t o = valid ? off[r] : 0u;
 		uint32_t n = valid ? off[r + 1] - o : 0u;
 		if (valid && n == 0 && do_consensus && li == 0) {
 			recs[r].hit = -2;
 			recs[r].matches = 0;
 		}
-		if (valid && (n > (uint32_t)G || !lds_ok)) {
-			if (li == 0)
-				next_list[atomicAdd(next_count, 1u)] = r;
-			n = 0; // not ours
+		const bool pass_on = valid && (n > (uint32_t)G || !lds_ok);
+		if (G == 64) {
+			if (pass_on && li == 0)
+				next_list[atomicAdd(next_count, 1u)] = r; // rare (> 64 hits): one atomic each is fine
+		} else {
+			// a third of the reads take this exit: list slots come in chunks of 64 per wave (a single hot
+			// counter sustains only ~90 M atomics/s); unused slots of a chunk are closed with kNoRead
+			const unsigned long long pm = __ballot(pass_on && li == 0);
+			if (pm) {
+				const uint32_t cnt = (uint32_t)__popcll(pm);
+				if (chunk_used + cnt > 64u) {
+					if (lane == 0) {
+						for (uint32_t k = chunk_used; k < 64u; k++)
+							next_list[chunk_base + k] = kNoRead;
+						chunk_base = atomicAdd(next_count, 64u);
+					}
+					chunk_base = __shfl(chunk_base, 0);
+					chunk_used = 0;
+				}
+				if (pass_on && li == 0)
+					next_list[chunk_base + chunk_used + (uint32_t)__popcll(pm & ((1ull << lane) - 1))] = r;
+				chunk_used += cnt;
+			}
 		}
+		if (pass_on)
+			n = 0; // not ours
 		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
 		const uint32_t st0 = n ? read_start[r] : 0u;
 		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
@@ -1117,34 +1137,60 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 				rcode[b] = 0xFFFFFFFEu;
 		}
 		lds_fence();
-		// best score of the hit's subject
+		if (cv.dbg == 1) {
+			if (mine)
+				hits[o + li] = h;
+			continue;
+		}
+		// best score of the hit's subject.  Loops run a wave-uniform number of rounds, four LDS rows in
+		// flight per round; rows past a read's end (stale bytes) are masked by j < n.
+		const uint32_t nmax = RPW == 2 ? max(__shfl(n, 0), __shfl(n, 32)) : n;
 		int best = h.score;
-		if (mine) {
-			for (uint32_t j = 0; j < n; j++)
-				if (sw->a.subj[slot0 + j] == h.subject && sw->a.score[slot0 + j] > best)
-					best = sw->a.score[slot0 + j];
+		for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
+			int sj[4], sc[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				sj[u] = sw->a.subj[slot0 + ((j0 + u) & (G - 1))];
+				sc[u] = sw->a.score[slot0 + ((j0 + u) & (G - 1))];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (j0 + u < n && sj[u] == h.subject && sc[u] > best)
+					best = sc[u];
 		}
 		const SortKey kx = make_key(h, best);
 		lds_fence();
+		if (cv.dbg == 2) {
+			if (mine) {
+				h.score = best;
+				hits[o + li] = h;
+			}
+			continue;
+		}
 		if (mine) {
 			sw->a.k1[slot0 + li] = kx.k1;
 			sw->a.k2[slot0 + li] = kx.k2;
-			sw->a.k3[slot0 + li] = kx.k3;
 		}
 		lds_fence();
-		// rank = number of hits that precede this one
+		// rank = number of hits that precede this one (ties, which the search cannot produce, by slot)
 		uint32_t rank = 0;
-		if (mine) {
-			for (uint32_t j = 0; j < n; j++) {
-				SortKey kj;
-				kj.k1 = sw->a.k1[slot0 + j];
-				kj.k2 = sw->a.k2[slot0 + j];
-				kj.k3 = sw->a.k3[slot0 + j];
-				rank += key_less(kj, kx) || (!key_less(kx, kj) && j < (uint32_t)li);
+		for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
+			uint64_t a1[4], a2[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
+				a2[u] = sw->a.k2[slot0 + ((j0 + u) & (G - 1))];
 			}
-			hits[o + rank] = h;
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const uint32_t j = j0 + u;
+				const bool before = (a1[u] < kx.k1) | ((a1[u] == kx.k1) & ((a2[u] < kx.k2) | ((a2[u] == kx.k2) & (j < (uint32_t)li))));
+				rank += (before & (j < n)) ? 1u : 0u;
+			}
 		}
-		if (!do_consensus)
+		if (mine)
+			hits[o + rank] = h;
+		if (!do_consensus || cv.dbg == 3)
 			continue;
 		uint32_t rmv = 0, ntok = 0, sim = 0;
 		if (mine) {
@@ -1159,7 +1205,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
 		}
 		lds_fence();
-		if (li == 0 && n) {
+		if (li == 0 && n && cv.dbg != 4) {
 			// Consensus:186-204, strictly in table order
 			pgx_consensus_rec rec;
 			rec.hit = -1;
@@ -1169,9 +1215,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			} else {
 				ArgmaxState am;
 				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
-				for (uint32_t k = 0; k < n; k++)
-					am.step_keys((int32_t)(o + k), sw->b.rm[slot0 + k], sw->b.krm[slot0 + k], sw->b.kcnt[slot0 + k],
-						     sw->b.sim[slot0 + k]);
+				for (uint32_t k0 = 0; k0 < n; k0 += 4) {
+					uint32_t vrm[4], vsim[4];
+					uint64_t vkrm[4], vkcnt[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const uint32_t k = slot0 + ((k0 + u) & (G - 1));
+						vrm[u] = sw->b.rm[k];
+						vsim[u] = sw->b.sim[k];
+						vkrm[u] = sw->b.krm[k];
+						vkcnt[u] = sw->b.kcnt[k];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; u++)
+						if (k0 + u < n)
+							am.step_keys((int32_t)(o + k0 + u), vrm[u], vkrm[u], vkcnt[u], vsim[u]);
+				}
 				rec.hit = am.win;
 				rec.matches = (int32_t)am.maxrm;
 			}
@@ -1179,6 +1238,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		lds_fence();
 	}
+	if (G != 64 && lane == 0 && chunk_used < 64u && chunk_used > 0)
+		for (uint32_t k = chunk_used; k < 64u; k++)
+			next_list[chunk_base + k] = kNoRead;
 }
 
 // Reads with more hits than the LDS path holds: one block per read, all-pairs ranking through
@@ -1296,6 +1358,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 {
 	ConsView cv;
 	memset(&cv, 0, sizeof cv);
+	cv.dbg = getenv("PGX_SORT_STOP") ? atoi(getenv("PGX_SORT_STOP")) : 0;
 	if (db && db->bound) {
 		cv.subj_tok_off = db->d_subj_tok_off.data();
 		cv.subj_tok = db->d_subj_tok.data();
@@ -1461,7 +1524,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	// two reads per wavefront first; reads with 33..64 hits go through `mid_list` to the one-read-per-wave launch,
 	// which passes reads with more than 64 hits on to `big_list`
 	DevBuf<uint32_t> &mid_list = g_ws.mid_list, &mid_count = g_ws.mid_count;
-	PGX_TRY(mid_list.ensure(n));
+	PGX_TRY(mid_list.ensure(n + 64ull * kWavesPerBlock * 256 * 8)); // + one open chunk per wave
 	PGX_TRY(mid_count.ensure(1));
 	PGX_HIP(hipMemsetAsync(mid_count.data(), 0, sizeof(uint32_t), 0));
 	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
