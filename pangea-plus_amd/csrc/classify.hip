@@ -1197,44 +1197,56 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			rmv = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
 			sim = hit_simrank(cv, h);
 		}
-		lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
-		if (mine) {
-			sw->b.rm[slot0 + rank] = rmv;
-			sw->b.sim[slot0 + rank] = sim;
-			sw->b.krm[slot0 + rank] = dec_str_key(rmv);
-			sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
+		// Consensus:186-204 is an order-dependent selection (ArgmaxState).  When every hit of the read has
+		// the same lineage token count c >= 1 -- the normal case -- it has a closed form: after the first
+		// step maxcount stays c, so the winner is, among the hits whose agreement count is the text-order
+		// maximum, the first one in table order whose pident text is greatest.  That is two reductions
+		// over the read's lanes; anything else takes the literal walk below.
+		const uint32_t c0 = __shfl(ntok, slot0);
+		const bool odd = mine && (ntok != c0 || ntok == 0u || rmv >= 100000000u || sim >= (1u << 25));
+		const unsigned long long odd_mask = __ballot(odd);
+		const unsigned long long gmask = G == 64 ? ~0ull : (g ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+		const bool slow = (odd_mask & gmask) != 0ull;
+		const bool present = !n || !cv.rdp_present || cv.rdp_present[r];
+		if (n && !present && li == 0) {
+			recs[r].hit = -2;
+			recs[r].matches = 0;
 		}
-		lds_fence();
-		if (li == 0 && n && cv.dbg != 4) {
-			// Consensus:186-204, strictly in table order
-			pgx_consensus_rec rec;
-			rec.hit = -1;
-			rec.matches = 0;
-			if (cv.rdp_present && !cv.rdp_present[r]) {
-				rec.hit = -2;
-			} else {
+		if (cv.dbg != 4) {
+			const uint32_t k32 = mine ? dec_str_key32(rmv) : 0u; // >= 1 for any value
+			uint32_t kmax = k32;
+#pragma unroll
+			for (int m = 1; m < G; m <<= 1)
+				kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
+			const bool elig = mine && k32 == kmax;
+			const uint32_t key2 = elig ? ((sim << 6) | (63u - rank)) + 1u : 0u;
+			uint32_t top = key2;
+#pragma unroll
+			for (int m = 1; m < G; m <<= 1)
+				top = max(top, (uint32_t)__shfl_xor(top, m));
+			if (elig && key2 == top && present && !slow) {
+				recs[r].hit = (int32_t)(o + rank);
+				recs[r].matches = (int32_t)rmv;
+			}
+		}
+		if (odd_mask) {
+			lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
+			if (mine) {
+				sw->b.rm[slot0 + rank] = rmv;
+				sw->b.sim[slot0 + rank] = sim;
+				sw->b.krm[slot0 + rank] = dec_str_key(rmv);
+				sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
+			}
+			lds_fence();
+			if (li == 0 && n && slow && present) {
 				ArgmaxState am;
 				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
-				for (uint32_t k0 = 0; k0 < n; k0 += 4) {
-					uint32_t vrm[4], vsim[4];
-					uint64_t vkrm[4], vkcnt[4];
-#pragma unroll
-					for (int u = 0; u < 4; u++) {
-						const uint32_t k = slot0 + ((k0 + u) & (G - 1));
-						vrm[u] = sw->b.rm[k];
-						vsim[u] = sw->b.sim[k];
-						vkrm[u] = sw->b.krm[k];
-						vkcnt[u] = sw->b.kcnt[k];
-					}
-#pragma unroll
-					for (int u = 0; u < 4; u++)
-						if (k0 + u < n)
-							am.step_keys((int32_t)(o + k0 + u), vrm[u], vkrm[u], vkcnt[u], vsim[u]);
-				}
-				rec.hit = am.win;
-				rec.matches = (int32_t)am.maxrm;
+				for (uint32_t k = 0; k < n; k++)
+					am.step_keys((int32_t)(o + k), sw->b.rm[slot0 + k], sw->b.krm[slot0 + k], sw->b.kcnt[slot0 + k],
+						     sw->b.sim[slot0 + k]);
+				recs[r].hit = am.win;
+				recs[r].matches = (int32_t)am.maxrm;
 			}
-			recs[r] = rec;
 		}
 		lds_fence();
 	}

@@ -44,6 +44,14 @@ __device__ __forceinline__ uint64_t dec_str_key(uint32_t v)
 	return ((uint64_t)v * p10[10 - d]) * 16ull + (uint64_t)d;
 }
 
+// the same order in 32 bits, for v < 10^8
+__device__ __forceinline__ uint32_t dec_str_key32(uint32_t v)
+{
+	const uint32_t p10[9] = { 1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u };
+	const int d = dec_digits(v);
+	return (v * p10[8 - d]) * 16u + (uint32_t)d;
+}
+
 // number of (a,b) with blasttax[a+1] eq clean(rdptax[b]) and index1 eq index2 (Consensus:154-184).
 // tok: the hit's lineage tokens (rank,name,rank,name,...); token id 0 is the empty string, which is
 // also what an undefined name compares as; rank index -1 is undef on either side.

@@ -89,3 +89,47 @@ def test_pident_rounding_equals_printf(pg):
                 got = q + 1 if s > 0 else (q if s < 0 else q + (q & 1))
             bad += got != want
     assert bad == 0
+
+
+def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_bin):
+    """Lineages of different depth inside one read's hits and agreement counts of two digits: the
+    order-dependent selection of Consensus:186-204 has no closed form there (k_sort_consensus's literal walk)
+    and Perl's text comparison of the counts ("10" lt "9") decides."""
+    from pangea_plus_amd import _capi
+    tdir = tmp_path / "Tax_class"
+    tdir.mkdir()
+    for f in ("names.dmp", "gi_taxid_nucl.dmp"):
+        (tdir / f).write_bytes((chain / "Tax_class" / f).read_bytes())
+    out = []
+    for line in (chain / "Tax_class" / "nodes.dmp").read_text().splitlines(True):
+        cols = line.split("\t|\t")
+        if cols[2] == "species" and int(cols[0]) % 3 == 0:
+            cols[2] = "no rank"          # every third species loses its rank: shorter lineage text
+        if cols[2] == "genus" and int(cols[0]) % 5 == 0:
+            cols[2] = "subgenus"
+        out.append("\t|\t".join(cols))
+    (tdir / "nodes.dmp").write_text("".join(out))
+    assert run_cmd([oracle_bin, "tax_class", "-c"], cwd=tdir)[0] == 0
+    rows = (chain / "rdp.tsv").read_text().splitlines()
+    for i in range(0, len(rows), 4):     # every fourth read names its triplets three times over
+        head, trip = rows[i].split("\t", 5)[:5], rows[i].split("\t", 5)[5]
+        rows[i] = "\t".join(head + [trip, trip, trip])
+    (tmp_path / "rdp.tsv").write_text("\n".join(rows) + "\n")
+    assert run_cmd([oracle_bin, "taxcollector", "-f", str(chain / "hits.tsv"), "-o", str(tmp_path / "hits_class.tsv"),
+                    "-d", str(tdir)], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "consensus", "-b", str(tmp_path / "hits_class.tsv"), "-r", str(tmp_path / "rdp.tsv"),
+                    "-o", str(tmp_path / "consensus.txt")], timeout=600)[0] == 0
+    want = (tmp_path / "consensus.txt").read_bytes()
+    assert want != (chain / "consensus.txt").read_bytes()
+
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(tdir)))
+    reads = pg.Reads.from_synth(cfg, 0, N)
+    rdp = pg.Rdp.from_file(str(tmp_path / "rdp.tsv"), reads, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    assert _capi.consensus_format(db, reads, hits, recs) == want
+    assert int((recs["matches"] >= 10).sum()) > 0
+    # and the file verb on the same tables
+    pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
+    assert (tmp_path / "c2.txt").read_bytes() == want
