@@ -28,6 +28,7 @@ namespace pgx {
 struct DbView {
 	const uint64_t *words, *amb;
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
+	const uint4 *blk_info;
 	uint32_t n_seq;
 	int bits;
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
@@ -693,15 +694,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				// stage 2: block table entry of the posting, and the 13 database bases left and 12 right of
 				// the 16-mer against the read's (one 8-byte load each; the read's come from L1)
 				uint32_t xl[kDeal], xr[kDeal];
+				uint4 bi[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					p[u] = raw[u] & 0x7FFFFFFFu;
 					keep[u] = active[u];
 					tested[u] = false;
 					xl[u] = xr[u] = 0;
-					sj[u] = 0;
+					bi[u] = make_uint4(0, 0, 0, 0);
 					if (active[u]) {
-						sj[u] = db.blk_subj[p[u] >> kBlkShift];
+						bi[u] = db.blk_info[p[u] >> kBlkShift];
 						if (!AMB) {
 							const uint64_t *rwp = (o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA);
 							if (o_qpos[u] >= kProbeStride) {
@@ -733,16 +735,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						if (la + ra < kWord - kSeedK)
 							keep[u] = false;
 					}
-					s0[u] = s1[u] = 0;
-					if (keep[u]) {
-						uint32_t a = db.seq_off[sj[u]], b = db.seq_off[sj[u] + 1];
-						while (b <= p[u]) {
+					// the posting's subject: the block's first subject, or (a boundary inside the block) the next
+					// one; only blocks holding three or more subjects walk seq_off
+					sj[u] = bi[u].x;
+					s0[u] = bi[u].y;
+					s1[u] = bi[u].z;
+					if (keep[u] && s1[u] <= p[u]) {
+						sj[u]++;
+						s0[u] = s1[u];
+						s1[u] = bi[u].w;
+						while (s1[u] <= p[u]) {
 							sj[u]++;
-							a = b;
-							b = db.seq_off[sj[u] + 1];
+							s0[u] = s1[u];
+							s1[u] = db.seq_off[sj[u] + 1];
 						}
-						s0[u] = a;
-						s1[u] = b;
 					}
 				}
 				if (db.dbg_stop == 2) {
@@ -1345,6 +1351,7 @@ static DbView db_view(const pgx_db *db)
 	v.amb = db->has_amb ? db->d_amb.data() : nullptr;
 	v.seq_off = db->d_seq_off.data();
 	v.blk_subj = db->d_blk_subj.data();
+	v.blk_info = db->d_blk_info.data();
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;

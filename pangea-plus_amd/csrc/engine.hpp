@@ -27,6 +27,7 @@ struct pgx_db {
 
 	pgx::DevBuf<uint64_t> d_words, d_amb;
 	pgx::DevBuf<uint32_t> d_seq_off, d_blk_subj;
+	pgx::DevBuf<uint4> d_blk_info; // per 512-base block: subject, its start, its end, the next subject's end
 	int index_bits = 0;
 	int64_t n_postings = 0;
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
@@ -87,6 +88,7 @@ namespace pgx {
 
 // seqdb.hip
 int db_upload_and_index(pgx_db *db);
+int db_build_blk_info(pgx_db *db);
 int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
 			pgx_reads **out);
 int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);
