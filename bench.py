@@ -38,8 +38,8 @@ def algorithmic_bytes(n_reads, st, read_len):
     words = (read_len + 31) // 32
     per_read = 2 * 8 * words + 8 + 4         # both packed strands, length/offset, per-read hit count
     per_probe = 8                             # one bucket_off pair
-    per_posting = 4 + 4 + 4 + 4               # posting, the 13 bases left and 12 bases right of its 16-mer (filters), block-table entry
-    per_survivor = 8 + 8 * (words + 1)        # seq_off pair + the database window of the diagonal
+    per_posting = 4 + 4 + 4                   # posting + its context record (database bases left / right of the 16-mer)
+    per_survivor = 16 + 8 * (words + 1)       # block-table record (subject, bounds) + the database window of the diagonal
     per_hit = 32
     return (n_reads * per_read + st.probes * per_probe + st.postings * per_posting + st.survivors * per_survivor
             + st.hits * per_hit)

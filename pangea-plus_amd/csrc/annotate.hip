@@ -483,6 +483,7 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	PGX_TRY(db->d_node_name_tok.alloc(nn.size()));
 	PGX_TRY(db->d_node_name_tok.upload(nn.data(), nn.size()));
 	db->bound = true;
+	index_check(db, "bind_taxonomy");
 	return 0;
 }
 
@@ -634,6 +635,7 @@ int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, c
 		delete rd;
 		return rc;
 	}
+	index_check(db, "rdp_from_synth");
 	*out = rd;
 	return 0;
 }

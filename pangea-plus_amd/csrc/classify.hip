@@ -29,6 +29,7 @@ struct DbView {
 	const uint64_t *words, *amb;
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
 	const uint4 *blk_info;
+	const uint2 *post_ctx;
 	uint32_t n_seq;
 	int bits;
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
@@ -688,32 +689,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 					o_rs[u] = o / LPR;
 				}
 				uint32_t raw[kDeal];
+				uint2 ctx[kDeal];
 #pragma unroll
-				for (int u = 0; u < kDeal; u++)
+				for (int u = 0; u < kDeal; u++) {
 					raw[u] = active[u] ? db.postings[pidx[u]] : 0u;
-				// stage 2: block table entry of the posting, and the 13 database bases left and 12 right of
-				// the 16-mer against the read's (one 8-byte load each; the read's come from L1)
+					ctx[u] = make_uint2(0u, 0u);
+					if (!AMB && active[u])
+						ctx[u] = db.post_ctx[pidx[u]];
+				}
+				// stage 2: the 13 database bases left and the 12 right of the 16-mer (post_ctx, fetched beside
+				// the posting) against the read's (L1)
 				uint32_t xl[kDeal], xr[kDeal];
-				uint4 bi[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					p[u] = raw[u] & 0x7FFFFFFFu;
 					keep[u] = active[u];
 					tested[u] = false;
 					xl[u] = xr[u] = 0;
-					bi[u] = make_uint4(0, 0, 0, 0);
-					if (active[u]) {
-						bi[u] = db.blk_info[p[u] >> kBlkShift];
-						if (!AMB) {
-							const uint64_t *rwp = (o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA);
-							if (o_qpos[u] >= kProbeStride) {
-								// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
-								tested[u] = !(raw[u] >> 31);
-								xl[u] = window16(db.words, (int64_t)p[u] - kProbeStride) ^
-									window16(rwp, o_qpos[u] - kProbeStride);
-							}
-							xr[u] = window16(db.words, (int64_t)p[u] + kSeedK) ^ window16(rwp, o_qpos[u] + kSeedK);
+					if (!AMB && active[u]) {
+						const uint64_t *rwp = (o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA);
+						if (o_qpos[u] >= kProbeStride) {
+							// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
+							tested[u] = !(raw[u] >> 31);
+							xl[u] = ctx[u].x ^ window16(rwp, o_qpos[u] - kProbeStride);
 						}
+						xr[u] = ctx[u].y ^ window16(rwp, o_qpos[u] + kSeedK);
 					}
 				}
 				// stage 3: la / ra = matching bases immediately left / right of the 16-mer (capped at 13 / 12,
@@ -735,8 +735,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						if (la + ra < kWord - kSeedK)
 							keep[u] = false;
 					}
-					// the posting's subject: the block's first subject, or (a boundary inside the block) the next
-					// one; only blocks holding three or more subjects walk seq_off
+				}
+				// stage 4: subject and bounds of the survivors: the block's first subject, or (a boundary inside
+				// the block) the next one; only blocks holding three or more subjects walk seq_off
+				uint4 bi[kDeal];
+#pragma unroll
+				for (int u = 0; u < kDeal; u++)
+					bi[u] = keep[u] ? db.blk_info[p[u] >> kBlkShift] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+				for (int u = 0; u < kDeal; u++) {
 					sj[u] = bi[u].x;
 					s0[u] = bi[u].y;
 					s1[u] = bi[u].z;
@@ -1352,6 +1359,7 @@ static DbView db_view(const pgx_db *db)
 	v.seq_off = db->d_seq_off.data();
 	v.blk_subj = db->d_blk_subj.data();
 	v.blk_info = db->d_blk_info.data();
+	v.post_ctx = db->has_amb ? nullptr : db->d_post_ctx.data();
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;
@@ -1451,6 +1459,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		out->n_hits = 0;
 		return 0;
 	}
+	index_check(db, "search_pipeline");
 	const DbView dv = db_view(db);
 	const ReadsView rv = reads_view(rd);
 	const bool amb = db->has_amb || rd->has_amb;
@@ -1490,6 +1499,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			hipLaunchKernelGGL((k_seed_extend<false, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
 		else
 			hipLaunchKernelGGL((k_seed_extend<false, false>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+		trace_point("k_seed_extend");
 		PGX_HIP(hipGetLastError());
 		g_times.seed_extend_ms = t.stop();
 		PGX_TRY(counters.download(h_cnt, 8));
@@ -1532,6 +1542,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		PGX_HIP(hipGetLastError());
 	}
 	g_times.group_ms = t.stop();
+	trace_point("group");
 
 	// per-read order (+ consensus)
 	t.start();
@@ -1551,10 +1562,12 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	hipLaunchKernelGGL(k_sort_consensus<32>, dim3(grid2), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
 			   read_start.data(), out->d_read_off.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv,
 			   rdp ? 1 : 0, lds_ok, d_recs, mid_list.data(), mid_count.data());
+	trace_point("k_sort_consensus<32>");
 	hipLaunchKernelGGL(k_sort_consensus<64>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
 			   read_start.data(), out->d_read_off.data(), (uint32_t)n, mid_list.data(), mid_count.data(), cv, rdp ? 1 : 0,
 			   lds_ok, d_recs, big_list.data(), big_count.data());
 	PGX_HIP(hipGetLastError());
+	trace_point("k_sort_consensus<64>");
 	uint32_t n_big = 0;
 	PGX_TRY(big_count.download(&n_big, 1));
 	if (n_big) {

@@ -108,6 +108,17 @@ int write_text_file(const char *path, const std::string &s)
 	return 0;
 }
 
+// debugging aid (PGX_TRACE=1): synchronise and report after a stage, so a device fault names its kernel
+void trace_point(const char *what)
+{
+	static const bool on = getenv("PGX_TRACE") != nullptr;
+	if (!on)
+		return;
+	const hipError_t e = hipDeviceSynchronize();
+	fprintf(stderr, "[pgx trace] %s: %s\n", what, hipGetErrorString(e));
+	fflush(stderr);
+}
+
 } // namespace pgx
 
 extern "C" {

@@ -114,4 +114,6 @@ struct Text {
 std::string read_text_file(const char *path, bool *ok);
 int write_text_file(const char *path, const std::string &s);
 
+void trace_point(const char *what);
+
 } // namespace pgx

@@ -31,6 +31,7 @@ struct pgx_db {
 	int index_bits = 0;
 	int64_t n_postings = 0;
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
+	pgx::DevBuf<uint2> d_post_ctx; // per posting: database bases left / right of the 16-mer (databases without ambiguity)
 
 	// taxonomy binding (pgx_db_bind_taxonomy): per subject lineage text + consensus tokens
 	bool bound = false;
@@ -89,6 +90,7 @@ namespace pgx {
 // seqdb.hip
 int db_upload_and_index(pgx_db *db);
 int db_build_blk_info(pgx_db *db);
+void index_check(const pgx_db *db, const char *where);
 int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
 			pgx_reads **out);
 int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);

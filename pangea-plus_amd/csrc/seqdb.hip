@@ -5,7 +5,6 @@
 // `2bwt-builder ref.fasta` (README.md:130); both reference tools are external/closed, the
 // format here is the build's own.
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 
@@ -232,6 +231,20 @@ __global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, 
 	}
 }
 
+// post_ctx[i] = the database around posting i, in index order: x = the 16 bases from 13 left of the 16-mer,
+// y = the 16 bases right of it.  k_seed_extend's duplicate and short-run filters read them from this
+// contiguous stream instead of fetching a random database line per posting.
+__global__ void k_post_ctx(const uint64_t *__restrict__ words, const uint32_t *__restrict__ postings, uint64_t n,
+			   uint2 *__restrict__ ctx)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		const int64_t p = (int64_t)(postings[i] & 0x7FFFFFFFu);
+		ctx[i] = make_uint2(window16(words, p - kProbeStride), window16(words, p + kSeedK));
+	}
+}
+
 // run heads of the sorted keys write the run length into counts[key]
 __global__ void k_bucket_counts(const uint32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ counts)
 {
@@ -260,6 +273,147 @@ __global__ void k_bucket_counts(const uint32_t *__restrict__ keys, uint64_t n, u
 		}
 		counts[k] = (uint32_t)(lo + 1 - i);
 	}
+}
+
+// ---- exclusive scan of a uint32 table of any length (tiles of 4096: 256 threads x 16 consecutive entries)
+constexpr uint64_t kTile = 4096;
+
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t *lds, uint32_t *total)
+{
+	// 256 threads; returns the exclusive prefix of v over the block, *total = block sum
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	uint32_t incl = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t x = __shfl_up(incl, d);
+		if (lane >= d)
+			incl += x;
+	}
+	if (lane == 63)
+		lds[w] = incl;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int k = 0; k < w; k++)
+		base += lds[k];
+	*total = lds[0] + lds[1] + lds[2] + lds[3];
+	__syncthreads();
+	return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_tile_sums(const uint32_t *__restrict__ a, uint64_t n, uint64_t n_tiles,
+						    uint32_t *__restrict__ tile_sum)
+{
+	__shared__ uint32_t lds[4];
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * 16;
+		uint32_t v = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			if (i0 + k < n)
+				v += a[i0 + k];
+		uint32_t tot;
+		(void)block_exclusive_256(v, lds, &tot);
+		if (threadIdx.x == 0)
+			tile_sum[tile] = tot;
+	}
+}
+
+// one block: exclusive scan of the tile sums in place
+__global__ __launch_bounds__(1024) void k_tile_top(uint32_t *__restrict__ tile_sum, uint64_t n_tiles)
+{
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t carry_s;
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	if (t == 0)
+		carry_s = 0;
+	__syncthreads();
+	for (uint64_t base = 0; base < n_tiles; base += 1024) {
+		const uint64_t i = base + t;
+		const uint32_t v = i < n_tiles ? tile_sum[i] : 0u;
+		uint32_t incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			uint32_t x = __shfl_up(incl, d);
+			if (lane >= d)
+				incl += x;
+		}
+		if (lane == 63)
+			wsum[w] = incl;
+		__syncthreads();
+		uint32_t pre = carry_s;
+		for (int k = 0; k < w; k++)
+			pre += wsum[k];
+		if (i < n_tiles)
+			tile_sum[i] = pre + incl - v;
+		__syncthreads();
+		if (t == 1023)
+			carry_s = pre + incl;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256) void k_tile_scan(uint32_t *__restrict__ a, uint64_t n, uint64_t n_tiles,
+						    const uint32_t *__restrict__ tile_sum)
+{
+	__shared__ uint32_t lds[4];
+	for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * 16;
+		uint32_t x[16], v = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			x[k] = i0 + k < n ? a[i0 + k] : 0u;
+			v += x[k];
+		}
+		uint32_t tot;
+		uint32_t run = tile_sum[tile] + block_exclusive_256(v, lds, &tot);
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (i0 + k < n)
+				a[i0 + k] = run;
+			run += x[k];
+		}
+	}
+}
+
+// debugging aid (PGX_TRACE=1): structural check of the seed index
+__global__ void k_index_check(const uint32_t *__restrict__ bucket_off, uint64_t nb, const uint32_t *__restrict__ postings,
+			      uint64_t n_post, uint64_t n_bases, unsigned long long *__restrict__ bad)
+{
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t k = i; k < nb; k += stride)
+		if (bucket_off[k] > bucket_off[k + 1] || bucket_off[k + 1] > n_post) {
+			atomicAdd(&bad[0], 1ull);
+			atomicMin(&bad[2], (unsigned long long)k);
+			atomicMax(&bad[3], (unsigned long long)k);
+		}
+	for (uint64_t k = i; k < n_post; k += stride)
+		if ((postings[k] & 0x7FFFFFFFu) + (uint64_t)kSeedK > n_bases)
+			atomicAdd(&bad[1], 1ull);
+}
+
+void index_check(const pgx_db *db, const char *where)
+{
+	if (!getenv("PGX_TRACE") || !db || db->n_postings == 0)
+		return;
+	DevBuf<unsigned long long> bad;
+	if (bad.alloc(4, 0, 0, true) < 0)
+		return;
+	const unsigned long long init[4] = { 0, 0, ~0ull, 0 };
+	bad.upload(init, 4);
+	hipLaunchKernelGGL(k_index_check, dim3(256 * 32), dim3(256), 0, 0, db->d_bucket_off.data(), 1ull << db->index_bits,
+			   db->d_postings.data(), (uint64_t)db->n_postings, (uint64_t)db->n_bases, bad.data());
+	unsigned long long h[4] = { 0, 0, 0, 0 };
+	bad.download(h, 4);
+	fprintf(stderr, "[pgx trace] index check at %s: %llu bad bucket offsets (first %llu last %llu), %llu bad postings\n", where,
+		h[0], h[2], h[3], h[1]);
+	if (h[0]) {
+		uint32_t v[6];
+		const uint64_t k0 = h[2] >= 2 ? h[2] - 2 : 0;
+		db->d_bucket_off.download(v, 6, k0);
+		fprintf(stderr, "[pgx trace]   bucket_off[%llu..] = %u %u %u %u %u %u\n", (unsigned long long)k0, v[0], v[1], v[2], v[3], v[4], v[5]);
+	}
+	fflush(stderr);
 }
 
 int db_build_index(pgx_db *db)
@@ -291,15 +445,28 @@ int db_build_index(pgx_db *db)
 	PGX_HIP(hipGetLastError());
 	keys_in.release();
 	vals_in.release();
-	// exclusive scan of the counts in place -> bucket offsets; the extra last element becomes n
-	size_t scan_bytes = 0;
-	PGX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, db->d_bucket_off.data(), db->d_bucket_off.data(), 0u,
-					nb + 1, rocprim::plus<uint32_t>()));
-	DevBuf<uint8_t> tmp2;
-	PGX_TRY(tmp2.alloc(scan_bytes));
-	PGX_HIP(rocprim::exclusive_scan(tmp2.data(), scan_bytes, db->d_bucket_off.data(), db->d_bucket_off.data(), 0u,
-					nb + 1, rocprim::plus<uint32_t>()));
+	if (!db->has_amb) {
+		PGX_TRY(db->d_post_ctx.alloc(n));
+		hipLaunchKernelGGL(k_post_ctx, dim3(grid), dim3(256), 0, 0, db->d_words.data(), db->d_postings.data(), n,
+				   db->d_post_ctx.data());
+		PGX_HIP(hipGetLastError());
+	}
+	// exclusive scan of the counts in place -> bucket offsets; the extra last element becomes n.
+	// (Own three-pass scan with 64-bit indexing: the table has 2^32 + 1 entries at full size, and
+	// rocprim::exclusive_scan returned a doubled prefix for the last 4 097 of them.)
+	{
+		const uint64_t total = nb + 1, n_tiles = (total + kTile - 1) / kTile;
+		DevBuf<uint32_t> tile_sum;
+		PGX_TRY(tile_sum.alloc(n_tiles));
+		const int tg = (int)std::min<uint64_t>(n_tiles, 256 * 64);
+		hipLaunchKernelGGL(k_tile_sums, dim3(tg), dim3(256), 0, 0, db->d_bucket_off.data(), total, n_tiles, tile_sum.data());
+		hipLaunchKernelGGL(k_tile_top, dim3(1), dim3(1024), 0, 0, tile_sum.data(), n_tiles);
+		hipLaunchKernelGGL(k_tile_scan, dim3(tg), dim3(256), 0, 0, db->d_bucket_off.data(), total, n_tiles, tile_sum.data());
+		PGX_HIP(hipGetLastError());
+		PGX_HIP(hipDeviceSynchronize());
+	}
 	PGX_HIP(hipDeviceSynchronize());
+	index_check(db, "db_build_index");
 	return 0;
 }
 
@@ -872,6 +1039,7 @@ int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count,
 		delete rd;
 		return rc;
 	}
+	trace_point("reads_from_synth");
 	*out = rd;
 	return 0;
 }
@@ -937,6 +1105,8 @@ int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
 	add("blk_subj", db->d_blk_subj.data(), db->d_blk_subj.bytes());
 	add("bucket_off", db->d_bucket_off.data(), db->d_bucket_off.bytes());
 	add("postings", db->d_postings.data(), db->d_postings.bytes());
+	if (!db->has_amb)
+		add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
 	return n;
 }
 
@@ -964,6 +1134,8 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 		rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
 	if (rc == 0)
 		rc = db->d_postings.alloc(db->n_postings ? (size_t)db->n_postings : 1);
+	if (rc == 0 && !db->has_amb)
+		rc = db->d_post_ctx.alloc(db->n_postings ? (size_t)db->n_postings : 1);
 	if (rc < 0) {
 		delete db;
 		return rc;

@@ -115,6 +115,43 @@ def test_direct_address_index_paths_match_oracle(pg, workload, oracle_bin, tmp_p
     assert _blast_text(pg, db, rd, tmp_path, "adjauto") == want.read_bytes()
 
 
+def test_direct_address_index_top_buckets(pg, oracle_bin, tmp_path, monkeypatch):
+    """16-mers ending in a run of T are the numerically largest keys: the last entries of the 2^32 + 1 bucket
+    table (a library scan once returned a doubled prefix for exactly the last 4 097 of them).  Poly-T / poly-A
+    stretches of 30-45 bases put seeds there on both strands."""
+    import random
+    rng = random.Random(33)
+    seqs = []
+    for i in range(12):
+        left = "".join(rng.choice("ACGT") for _ in range(260))
+        right = "".join(rng.choice("ACGT") for _ in range(260))
+        run = ("T" if i % 2 == 0 else "A") * rng.randrange(30, 46)
+        seqs.append(left + "G" + run + "C" + right)
+    db = tmp_path / "polyt.fa"
+    db.write_text("".join(">gi|%d|x|t%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for i in range(120):
+        s = seqs[i % len(seqs)]
+        o = rng.randrange(150, 330)
+        w = list(s[o:o + 150])
+        for p_ in rng.sample(range(150), rng.choice([0, 1, 2])):
+            w[p_] = rng.choice([b for b in "ACGT" if b != w[p_]])
+        w = "".join(w)
+        if i % 3 == 0:
+            w = "".join(comp[c] for c in reversed(w))
+        reads.append(">t%d\n%s\n" % (i, w))
+    rd = tmp_path / "polyt_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "polyt_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)])[0] == 0
+    assert len(want.read_bytes()) > 5000
+    monkeypatch.setenv("PGX_INDEX_BITS", "32")
+    assert _blast_text(pg, db, rd, tmp_path, "polyt32") == want.read_bytes()
+    monkeypatch.delenv("PGX_INDEX_BITS")
+    assert _blast_text(pg, db, rd, tmp_path, "polytauto") == want.read_bytes()
+
+
 def test_long_queries_ambiguity_codes_and_heavy_reads(pg, oracle_bin, tmp_path, monkeypatch):
     """1 400-bp queries (config 2 shape: lazy masks, >64 probes per strand), IUPAC codes on both sides, and a
     repeated database in which every read collects hundreds of hits (fragmented output, big-read ordering,

@@ -7,7 +7,7 @@ pg.init(0)
 cfg = pg.SynthCfg.default()
 db = pg.Db.from_synth(cfg)
 reads = pg.Reads.from_synth(cfg, 0, 10_000_000)
-for stop in (1, 2, 3, 4, 5, 6, 7, 0):
+for stop in [int(x) for x in os.environ.get('STOPS', '1,2,3,4,5,6,7,0').split(',')]:
     os.environ["PGX_SEED_STOP"] = str(stop)
     for it in range(2):
         h = _capi.blast_search(db, reads); st = _capi.stage_times(); del h
