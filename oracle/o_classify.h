@@ -109,6 +109,16 @@ int o_soap_files(const char *reads_fa, const char *ref_fa, const char *out_path,
 		 const o_soap_opts *opt);
 
 int o_classify_main(int argc, char **argv);
+
+/* ---------- Megaclust/megaclust2.pl, Megaclustable/megaclustable.pl (o_megaclust.c) ---------- */
+typedef struct {
+	const char *i, *o, *s, *e, *b, *c, *d; /* raw option texts, NULL = not given (getopts 'i:o:s:e:b:c:d:h') */
+	int h;
+} o_megaclust_opts;
+double o_perl_num(const char *s, size_t n);
+int o_megaclust2(const o_megaclust_opts *o, obuf *log);
+int o_megaclust2_main(int argc, char **argv, obuf *log);    /* argv[0] is the program name */
+int o_megaclustable_main(int argc, char **argv, obuf *log);
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@
  *   pgx_oracle tax_class [-c|-s GI|-g GI|-t TAXID|-n TAXID|-v|-h]   (cwd = dump dir, as ncbitc.c:7-13)
  *   pgx_oracle taxcollector -f in.tsv -o out.tsv [-d taxdir]        (taxdir defaults to ./Tax_class)
  *   pgx_oracle consensus -b blast_class.tsv -r rdp.tsv [-s soap] -o out.txt
+ *   pgx_oracle megaclust2 -i consensus.txt -o table.csv [-s -e -b -d -c -h]   (Megaclust/megaclust2.pl)
+ *   pgx_oracle megaclustable -m a.csv b.csv ... -t LEVEL -o table.txt          (Megaclustable/megaclustable.pl)
  */
 #include "o_common.h"
 #include "o_classify.h"
@@ -67,6 +69,14 @@ int main(int argc, char **argv)
 		return 2;
 	}
 	const char *verb = argv[1];
+	if (strcmp(verb, "megaclust2") == 0 || strcmp(verb, "megaclustable") == 0) {
+		obuf log;
+		obuf_init(&log);
+		int rc = verb[9] == '2' ? o_megaclust2_main(argc - 1, argv + 1, &log) : o_megaclustable_main(argc - 1, argv + 1, &log);
+		fwrite(log.p ? log.p : "", 1, log.n, stdout);
+		obuf_free(&log);
+		return rc < 0 ? 2 : 0;
+	}
 	if (strcmp(verb, "tax_class") == 0) {
 		obuf out, err;
 		obuf_init(&out);
