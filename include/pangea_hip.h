@@ -236,6 +236,28 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
 			 const pgx_consensus_rec *recs, int64_t n, char **text, size_t *len);
 
+/* ---- after the consensus ------------------------------------------------------
+ * Megaclust/megaclust2.pl:33-163 `-i consensus.txt -o table.csv [-s PCT] [-e EVALUE] [-b BITS] [-d DELIM] [-c X] [-h]`
+ * (README.md:176).  The option texts are passed as the script's getopts('i:o:s:e:b:c:d:h') would hold them (NULL =
+ * not given; Perl truth: "" and "0" count as not given, megaclust2.pl:48,61,66,71,139).  `log_text` receives the
+ * bytes the script prints on stdout (run summary :161-163, or its usage/complaint :37-58), malloc'd.
+ * The data lines of the table come in first-counted order; the script prints them in Perl hash order (`keys`, :155),
+ * which is not defined. */
+typedef struct {
+	const char *in_path;  /* -i */
+	const char *out_path; /* -o */
+	const char *s, *e, *b, *c, *d;
+	int help;             /* -h */
+} pgx_megaclust_opts;
+int pgx_megaclust_file(const pgx_megaclust_opts *o, char **log_text);
+/* the same table straight from the consensus records of a batch in HBM (in_path / out_path are ignored):
+ * `csv_text` is what megaclust2.pl would write for pgx_consensus_format()'s text of the same batch */
+int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs,
+			int64_t n, const pgx_megaclust_opts *o, char **csv_text, size_t *csv_len, char **log_text);
+/* Megaclustable/megaclustable.pl:17-128 `-m table.csv ... -t LEVEL -o out.txt` (README.md:185): argv is the
+ * script's @ARGV (no program name).  Byte-identical output file; `log_text` = its stdout. */
+int pgx_megaclustable(int argc, const char *const *argv, char **log_text);
+
 /* instrumentation for bench.py: HIP-event time (ms) of the kernels of the last pipeline call */
 typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;

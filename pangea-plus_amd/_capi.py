@@ -93,7 +93,7 @@ SYMBOLS = [
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus",
-    "pgx_consensus_format", "pgx_last_stage_times",
+    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable",
 ]
 
 
@@ -124,6 +124,9 @@ def _declare(L):
     sig("pgx_classify_consensus", C.c_int, [V, V, V, V, V, I64])
     sig("pgx_consensus_format", C.c_int, [V, V, V, V, I64, V, V])
     sig("pgx_tax_lineage_batch", C.c_int, [V, V, I64, V, V, V])
+    sig("pgx_megaclust_file", C.c_int, [V, V])
+    sig("pgx_megaclust_batch", C.c_int, [V, V, V, V, I64, V, V, V, V])
+    sig("pgx_megaclustable", C.c_int, [C.c_int, V, V])
     sig("pgx_free", None, [V])
     for name in ("pgx_db_close", "pgx_reads_close", "pgx_hits_close", "pgx_rdp_close", "pgx_tax_close"):
         sig(name, None, [V])
@@ -378,6 +381,28 @@ def consensus_format(db, reads, hits, recs):
     return _take_text(txt.value, ln.value)
 
 
+class _MegaclustOpts(C.Structure):
+    _fields_ = [("in_path", C.c_char_p), ("out_path", C.c_char_p), ("s", C.c_char_p), ("e", C.c_char_p), ("b", C.c_char_p),
+                ("c", C.c_char_p), ("d", C.c_char_p), ("help", C.c_int)]
+
+
+def _mc_opts(i=None, o=None, s=None, e=None, b=None, c=None, d=None, h=False):
+    t = lambda v: None if v is None else str(v).encode()  # noqa: E731  option texts, as on the command line
+    return _MegaclustOpts(_b(i), _b(o), t(s), t(e), t(b), t(c), t(d), 1 if h else 0)
+
+
+def megaclust_batch(db, reads, hits, recs, s=None, e=None, b=None, c=None, d=None):
+    """megaclust2.pl's table for the consensus records of a batch in HBM: (csv bytes, stdout bytes)."""
+    recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+    o = _mc_opts(None, None, s, e, b, c, d)
+    txt, ln, log = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    rc = lib().pgx_megaclust_batch(db.ptr, reads.ptr, hits.ptr, recs.ctypes.data, len(recs), C.byref(o), C.byref(txt),
+                                   C.byref(ln), C.byref(log))
+    out = _take_text(log.value)
+    _check(rc)
+    return _take_text(txt.value, ln.value), out
+
+
 def stage_times():
     t = StageTimes()
     _check(lib().pgx_last_stage_times(C.byref(t)))
@@ -420,6 +445,28 @@ def taxcollector(f, o, taxdir="./Tax_class"):
     """`perl NCBI-taxcollector-0.01.pl -f in -o out` (reference README.md:109); returns the stdout report."""
     with TaxDb.open(taxdir) as db:
         return db.collect_file(f, o)
+
+
+def megaclust2(i, o, s=None, e=None, b=None, c=None, d=None, h=False):
+    """`perl Megaclust/megaclust2.pl -i IN -o OUT [-s -e -b -d -c -h]` (reference README.md:176); returns its stdout."""
+    opts = _mc_opts(i, o, s, e, b, c, d, h)
+    log = C.c_void_p()
+    rc = lib().pgx_megaclust_file(C.byref(opts), C.byref(log))
+    text = _take_text(log.value)
+    _check(rc)
+    return text
+
+
+def megaclustable(argv):
+    """`perl Megaclustable/megaclustable.pl -m A.csv B.csv ... -t LEVEL -o OUT` (reference README.md:185); `argv` is the
+    word list after the script name; returns its stdout."""
+    words = [os.fsencode(str(w)) for w in argv]
+    arr = (C.c_char_p * max(1, len(words)))(*words)
+    log = C.c_void_p()
+    rc = lib().pgx_megaclustable(len(words), arr, C.byref(log))
+    text = _take_text(log.value)
+    _check(rc)
+    return text
 
 
 def consensus(b, r, o, s=None):

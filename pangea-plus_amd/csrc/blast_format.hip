@@ -121,6 +121,22 @@ void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t 
 		   h.send, ev, bs);
 }
 
+// the e-value and bit-score columns of a hit of raw score `score` for a query of `qlen` bases
+void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_nseq, std::string &evalue, std::string &bits)
+{
+	BlastStats st;
+	st.db_len = db_len;
+	st.db_nseq = db_nseq;
+	const double sp = search_space(st, qlen);
+	const double e = sp * std::exp(-st.lambda * (double)score + std::log(st.K));
+	const double b = (st.lambda * (double)score - std::log(st.K)) / std::log(2.0);
+	char ev[32], bs[32];
+	format_evalue(e, ev);
+	format_bitscore(b, bs);
+	evalue = ev;
+	bits = bs;
+}
+
 int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)
 {
 	std::vector<pgx_hit> hv((size_t)h->n_hits);
