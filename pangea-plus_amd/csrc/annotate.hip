@@ -482,6 +482,17 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	}
 	PGX_TRY(db->d_node_name_tok.alloc(nn.size()));
 	PGX_TRY(db->d_node_name_tok.upload(nn.data(), nn.size()));
+	{
+		// OTU ids for megaclust: one per distinct lineage text, plus one for the empty text of an empty line
+		std::unordered_map<std::string, uint32_t> lin_id;
+		std::vector<uint32_t> subj_lin(n);
+		db->lin_text.clear();
+		for (size_t i = 0; i < n; i++)
+			subj_lin[i] = intern_into(lin_id, db->lin_text, db->lineage[i]);
+		db->empty_lin = intern_into(lin_id, db->lin_text, std::string());
+		PGX_TRY(db->d_subj_lin.alloc(n ? n : 1));
+		PGX_TRY(db->d_subj_lin.upload(subj_lin.data(), n));
+	}
 	db->bound = true;
 	index_check(db, "bind_taxonomy");
 	return 0;

@@ -45,6 +45,10 @@ struct pgx_db {
 	pgx::DevBuf<uint32_t> d_subj_pairs;
 	std::vector<int8_t> h_tok_rank;
 	std::vector<int32_t> subj_taxid;
+	// distinct lineage texts (the OTUs megaclust counts): id per subject, text per id; the last id is the empty text
+	std::vector<std::string> lin_text;
+	pgx::DevBuf<uint32_t> d_subj_lin;
+	uint32_t empty_lin = 0;
 	pgx::DevBuf<uint32_t> d_node_name_tok;       // taxid -> token id of a one-word scientific name (else 0)
 	pgx::DevBuf<uint32_t> d_simrank_lut;         // pident hundredths -> string-order rank
 	pgx::DevBuf<uint32_t> d_simrank_len;         // [length * 256 + mismatches] -> the same rank, alignments < 256 long

@@ -496,13 +496,9 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
 	int rc = require_device();
 	if (rc < 0)
 		return done(rc);
-	// OTU ids: one per distinct lineage text of the bound database, plus one for the empty text of an empty line
-	std::unordered_map<std::string, uint32_t> lin_id;
-	std::vector<std::string> lin_text;
-	std::vector<uint32_t> subj_lin((size_t)db->n_seq);
-	for (size_t i = 0; i < (size_t)db->n_seq; i++)
-		subj_lin[i] = intern_text(lin_id, lin_text, db->lineage[i].data(), db->lineage[i].size());
-	const uint32_t empty_lin = intern_text(lin_id, lin_text, "", 0);
+	// OTU ids come with the taxonomy binding: one per distinct lineage text, plus one for the empty text
+	const std::vector<std::string> &lin_text = db->lin_text;
+	const uint32_t empty_lin = db->empty_lin;
 	// thresholds as integers.  pident: the text is "%.2f" of hundredths / 100
 	int h_min = 10001;
 	for (int h = 0; h <= 10000; h++) {
@@ -559,25 +555,23 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
 		}
 	}
 	DevBuf<pgx_consensus_rec> d_recs;
-	DevBuf<uint32_t> d_subj_lin, d_smin, d_lin, d_qid;
+	DevBuf<uint32_t> d_smin, d_lin, d_qid;
 	DevBuf<uint8_t> d_pass, d_line;
 	const size_t nn = n ? (size_t)n : 1;
 	rc = d_recs.alloc(nn);
-	if (rc == 0) rc = d_subj_lin.alloc(subj_lin.size() ? subj_lin.size() : 1);
 	if (rc == 0) rc = d_smin.alloc(s_min.size());
 	if (rc == 0) rc = d_lin.alloc(nn);
 	if (rc == 0) rc = d_pass.alloc(nn);
 	if (rc == 0) rc = d_line.alloc(nn);
 	if (rc == 0) rc = d_qid.alloc(nn);
 	if (rc == 0 && n) rc = d_recs.upload(recs, (size_t)n);
-	if (rc == 0) rc = d_subj_lin.upload(subj_lin.data(), subj_lin.size());
 	if (rc == 0) rc = d_smin.upload(s_min.data(), s_min.size());
 	if (rc == 0 && !unique_queries) rc = d_qid.upload(qid.data(), (size_t)n);
 	if (rc < 0)
 		return done(rc);
 	if (n) {
 		hipLaunchKernelGGL(k_mc_filter_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_recs.data(), hits->d_hits.data(),
-				   reads->d_len.data(), d_subj_lin.data(), (uint64_t)n, h_min, d_smin.data(), max_len, empty_pass, empty_lin,
+				   reads->d_len.data(), db->d_subj_lin.data(), (uint64_t)n, h_min, d_smin.data(), max_len, empty_pass, empty_lin,
 				   d_pass.data(), d_line.data(), d_lin.data());
 		if (hipGetLastError() != hipSuccess)
 			return done(fail(PGX_E_NODEVICE, "k_mc_filter_batch launch failed"));
