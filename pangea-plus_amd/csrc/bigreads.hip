@@ -1,0 +1,199 @@
+// Reads with more hits than one wavefront orders in LDS (> 64), of any size: a conserved 16S region against a 16S
+// collection gives a read tens of thousands of hits, so this path must not be quadratic.
+//
+// Spec S5 order = (best score of the subject desc, subject asc, score desc, qstart, qend, sstart, send).  It is
+// produced by four stable segmented radix sorts (one segment per read), least significant key first:
+//     1  sstart, then strand (minus before plus: with equal qstart/qend/sstart that is `send` ascending)
+//     2  qstart, qend
+//     3  subject asc, score desc      -> the head of every subject run holds the subject's best score
+//     4  best score desc
+// then the 500-subject cut (subjects are contiguous in the order) and the write-back into the hit table.
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include "engine.hpp"
+
+namespace pgx {
+
+constexpr uint32_t kFragmentedRead = 0xFFFFFFFFu; // read_start value of a read whose hits went through the overflow table
+
+__global__ void k_big_lens(const uint32_t *__restrict__ off, const uint32_t *__restrict__ big_list, uint32_t n_big,
+			   uint32_t *__restrict__ len)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n_big) {
+		const uint32_t r = big_list[k];
+		len[k] = off[r + 1] - off[r];
+	}
+	if (k == n_big)
+		len[k] = 0;
+}
+
+// one block per big read: its hits, from wherever the seed kernel left them, into the compact work table
+__global__ __launch_bounds__(256) void k_big_gather(const pgx_hit *__restrict__ hits, const pgx_hit *__restrict__ scratch,
+						     const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ off,
+						     const uint32_t *__restrict__ big_list, uint32_t n_big,
+						     const uint32_t *__restrict__ seg_off, pgx_hit *__restrict__ work,
+						     uint32_t *__restrict__ vals)
+{
+	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
+		const uint32_t r = big_list[k], o = off[r], n = off[r + 1] - o, g0 = seg_off[k];
+		const uint32_t st0 = read_start[r];
+		const pgx_hit *src = st0 == kFragmentedRead ? hits + o : scratch + st0;
+		for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+			work[g0 + j] = src[j];
+			vals[g0 + j] = g0 + j;
+		}
+	}
+}
+
+template <int PASS>
+__global__ void k_big_keys(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ best,
+			   uint32_t total, unsigned long long *__restrict__ keys)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= total)
+		return;
+	const uint32_t v = vals[g];
+	const pgx_hit h = work[v];
+	unsigned long long k;
+	if (PASS == 1)
+		k = ((unsigned long long)(uint32_t)h.sstart << 1) | (h.send > h.sstart ? 1ull : 0ull);
+	else if (PASS == 2)
+		k = ((unsigned long long)(uint32_t)h.qstart << 32) | (unsigned long long)(uint32_t)h.qend;
+	else if (PASS == 3)
+		k = ((unsigned long long)(uint32_t)h.subject << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)h.score);
+	else
+		k = (unsigned long long)(0xFFFFFFFFu - best[v]);
+	keys[g] = k;
+}
+
+// after pass 3 (subject asc, score desc inside a read): the head of a subject run carries the best score
+__global__ __launch_bounds__(256) void k_big_best(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
+						   const uint32_t *__restrict__ seg_off, uint32_t n_big, uint32_t *__restrict__ best)
+{
+	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
+		const uint32_t g0 = seg_off[k], g1 = seg_off[k + 1];
+		for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+			const uint32_t v = vals[g];
+			const int subj = work[v].subject;
+			uint32_t h = g;
+			while (h > g0 && work[vals[h - 1]].subject == subj)
+				h--;
+			best[v] = (uint32_t)work[vals[h]].score;
+		}
+	}
+}
+
+// final order back into the hit table; read_cnt = hits kept by the 500-subject limit (spec S5)
+__global__ __launch_bounds__(256) void k_big_write(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
+						    const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ off,
+						    const uint32_t *__restrict__ big_list, uint32_t n_big, pgx_hit *__restrict__ hits,
+						    uint32_t *__restrict__ read_cnt)
+{
+	__shared__ uint32_t s_warp[4];
+	__shared__ uint32_t s_carry, s_keep;
+	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
+		const uint32_t r = big_list[k], o = off[r], g0 = seg_off[k], n = seg_off[k + 1] - g0;
+		if (threadIdx.x == 0) {
+			s_carry = 0;
+			s_keep = n;
+		}
+		__syncthreads();
+		for (uint32_t base = 0; base < n; base += blockDim.x) {
+			const uint32_t j = base + threadIdx.x;
+			int flag = 0;
+			pgx_hit h;
+			if (j < n) {
+				h = work[vals[g0 + j]];
+				hits[o + j] = h;
+				flag = j == 0 || work[vals[g0 + j - 1]].subject != h.subject;
+			}
+			// running count of distinct subjects up to and including position j
+			const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+			const unsigned long long m = __ballot(flag);
+			const uint32_t in_wave = (uint32_t)__popcll(m & (lane == 63 ? ~0ull : ((2ull << lane) - 1)));
+			if (lane == 63)
+				s_warp[w] = (uint32_t)__popcll(m);
+			__syncthreads();
+			uint32_t before = s_carry;
+			for (int q = 0; q < w; q++)
+				before += s_warp[q];
+			const uint32_t subjects = before + in_wave;
+			if (j < n && flag && subjects == 501u)
+				atomicMin(&s_keep, j);
+			__syncthreads();
+			if (threadIdx.x == 0)
+				s_carry += s_warp[0] + s_warp[1] + s_warp[2] + s_warp[3];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+			read_cnt[r] = s_keep;
+		__syncthreads();
+	}
+}
+
+// hits: the ordered hit table (big reads' slots are rewritten); scratch/read_start: the seed kernel's table
+int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_start, const uint32_t *off, uint32_t *read_cnt,
+		   const uint32_t *big_list, uint32_t n_big)
+{
+	if (n_big == 0)
+		return 0;
+	DevBuf<uint32_t> seg;
+	PGX_TRY(seg.alloc((size_t)n_big + 1));
+	hipLaunchKernelGGL(k_big_lens, dim3((n_big + 1 + 255) / 256), dim3(256), 0, 0, off, big_list, n_big, seg.data());
+	PGX_HIP(hipGetLastError());
+	{
+		size_t bytes = 0;
+		PGX_HIP(rocprim::exclusive_scan(nullptr, bytes, seg.data(), seg.data(), 0u, (size_t)n_big + 1, rocprim::plus<uint32_t>()));
+		DevBuf<uint8_t> tmp;
+		PGX_TRY(tmp.alloc(bytes ? bytes : 1));
+		PGX_HIP(rocprim::exclusive_scan(tmp.data(), bytes, seg.data(), seg.data(), 0u, (size_t)n_big + 1, rocprim::plus<uint32_t>()));
+	}
+	uint32_t total = 0;
+	PGX_TRY(seg.download(&total, 1, n_big));
+	if (total == 0)
+		return 0;
+	DevBuf<pgx_hit> work;
+	DevBuf<uint32_t> va, vb, best;
+	DevBuf<unsigned long long> ka, kb;
+	PGX_TRY(work.alloc(total));
+	PGX_TRY(va.alloc(total));
+	PGX_TRY(vb.alloc(total));
+	PGX_TRY(best.alloc(total));
+	PGX_TRY(ka.alloc(total));
+	PGX_TRY(kb.alloc(total));
+	const unsigned seg_grid = std::min<uint32_t>(n_big, 256u * 16u);
+	hipLaunchKernelGGL(k_big_gather, dim3(seg_grid), dim3(256), 0, 0, hits, scratch, read_start, off, big_list, n_big, seg.data(),
+			   work.data(), va.data());
+	PGX_HIP(hipGetLastError());
+	size_t sort_bytes = 0;
+	PGX_HIP(rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, ka.data(), kb.data(), va.data(), vb.data(), total, n_big,
+						    seg.data(), seg.data() + 1, 0, 64));
+	DevBuf<uint8_t> sort_tmp;
+	PGX_TRY(sort_tmp.alloc(sort_bytes ? sort_bytes : 1));
+	const unsigned el_grid = (total + 255) / 256;
+	uint32_t *cur = va.data(), *nxt = vb.data();
+	auto sort_pass = [&](int end_bit) -> int {
+		PGX_HIP(hipGetLastError());
+		PGX_HIP(rocprim::segmented_radix_sort_pairs(sort_tmp.data(), sort_bytes, ka.data(), kb.data(), cur, nxt, total, n_big, seg.data(),
+							    seg.data() + 1, 0, end_bit));
+		std::swap(cur, nxt);
+		return 0;
+	};
+	hipLaunchKernelGGL(k_big_keys<1>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
+	PGX_TRY(sort_pass(33));
+	hipLaunchKernelGGL(k_big_keys<2>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
+	PGX_TRY(sort_pass(64));
+	hipLaunchKernelGGL(k_big_keys<3>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
+	PGX_TRY(sort_pass(64));
+	hipLaunchKernelGGL(k_big_best, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), n_big, best.data());
+	hipLaunchKernelGGL(k_big_keys<4>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
+	PGX_TRY(sort_pass(32));
+	hipLaunchKernelGGL(k_big_write, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), off, big_list, n_big, hits, read_cnt);
+	PGX_HIP(hipGetLastError());
+	PGX_HIP(hipDeviceSynchronize()); // the work tables are released on return
+	return 0;
+}
+
+} // namespace pgx

@@ -947,24 +947,6 @@ __global__ void k_scatter_hits(const pgx_hit *__restrict__ in, uint64_t n_hits, 
 }
 
 // ------------------------------------------------------------------------------------------ per-read order + consensus
-// spec S5 order inside one read; `ba`/`bb` are the best scores of the hits' subjects
-__device__ __forceinline__ bool hit_less(const pgx_hit &a, int ba, const pgx_hit &b, int bb)
-{
-	if (ba != bb)
-		return ba > bb;
-	if (a.subject != b.subject)
-		return a.subject < b.subject;
-	if (a.score != b.score)
-		return a.score > b.score;
-	if (a.qstart != b.qstart)
-		return a.qstart < b.qstart;
-	if (a.qend != b.qend)
-		return a.qend < b.qend;
-	if (a.sstart != b.sstart)
-		return a.sstart < b.sstart;
-	return a.send < b.send;
-}
-
 struct ConsView {
 	const uint32_t *subj_tok_off, *subj_tok; // per subject token ids
 	const int8_t *tok_rank;                  // token id -> index in "0".."6" or -1
@@ -1268,55 +1250,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			next_list[chunk_base + k] = kNoRead;
 }
 
-// Reads with more hits than the LDS path holds: one block per read, all-pairs ranking through
-// global memory (correct for any size; quadratic, a known cost for pathological reads).
-__global__ __launch_bounds__(256) void k_sort_big(const pgx_hit *__restrict__ in, pgx_hit *__restrict__ out,
-						  const uint32_t *__restrict__ off, uint32_t *__restrict__ read_cnt,
-						  const uint32_t *__restrict__ big_list, uint32_t n_big, int *__restrict__ best_ws)
-{
-	for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
-		const uint32_t r = big_list[bi], o = off[r], n = off[r + 1] - o;
-		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-			const int subj = in[o + i].subject;
-			int b = in[o + i].score;
-			for (uint32_t j = 0; j < n; j++)
-				if (in[o + j].subject == subj && in[o + j].score > b)
-					b = in[o + j].score;
-			best_ws[o + i] = b;
-		}
-		__syncthreads();
-		for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-			const pgx_hit h = in[o + i];
-			const int b = best_ws[o + i];
-			uint32_t rank = 0;
-			for (uint32_t j = 0; j < n; j++) {
-				const pgx_hit g = in[o + j];
-				const int bj = best_ws[o + j];
-				rank += (j != i) && (hit_less(g, bj, h, b) || (!hit_less(h, b, g, bj) && j < i));
-			}
-			out[o + rank] = h;
-		}
-		__syncthreads();
-		// spec S5: at most 500 subjects; subjects are contiguous in the order, dropped hits are its tail
-		if (threadIdx.x == 0) {
-			uint32_t keep = n, subjects = 0;
-			int prev = -1;
-			for (uint32_t k = 0; k < n; k++) {
-				const int sj = out[o + k].subject;
-				if (sj != prev) {
-					prev = sj;
-					if (++subjects > 500u) {
-						keep = k;
-						break;
-					}
-				}
-			}
-			read_cnt[r] = keep;
-		}
-		__syncthreads();
-	}
-}
-
 // consensus for the big reads and for file mode (hits already in order): one lane per read
 __global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint32_t *__restrict__ off,
 				   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ list, uint32_t n_list,
@@ -1571,14 +1504,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	uint32_t n_big = 0;
 	PGX_TRY(big_count.download(&n_big, 1));
 	if (n_big) {
-		DevBuf<int> best_ws;
-		PGX_TRY(best_ws.alloc(H));
-		// the scratch table still holds nothing we need: reuse it as the destination, then copy back
-		PGX_HIP(hipMemcpyAsync(scratch.data(), out->d_hits.data(), H * sizeof(pgx_hit), hipMemcpyDeviceToDevice, 0));
-		hipLaunchKernelGGL(k_sort_big, dim3(std::min<uint32_t>(n_big, 4096)), dim3(256), 0, 0, scratch.data(),
-				   out->d_hits.data(), out->d_read_off.data(), out->d_read_cnt.data(), big_list.data(), n_big,
-				   best_ws.data());
-		PGX_HIP(hipGetLastError());
+		// more than 64 hits (or reads too long for the packed keys): segmented radix sorts, any size (bigreads.hip)
+		PGX_TRY(sort_big_reads(out->d_hits.data(), scratch.data(), read_start.data(), out->d_read_off.data(),
+				       out->d_read_cnt.data(), big_list.data(), n_big));
 		if (rdp) {
 			hipLaunchKernelGGL(k_consensus_serial, dim3((n_big + 63) / 64), dim3(64), 0, 0, out->d_hits.data(),
 					   out->d_read_off.data(), out->d_read_cnt.data(), big_list.data(), n_big, cv, d_recs);

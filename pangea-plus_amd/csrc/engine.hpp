@@ -111,6 +111,10 @@ int blast_search_device(pgx_db *db, pgx_reads *reads, pgx_hits *out, pgx_stage_t
 int consensus_device(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *d_out,
 		     pgx_stage_times *times);
 
+// bigreads.hip: spec order + 500-subject cut for reads with more than 64 hits
+int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_start, const uint32_t *off, uint32_t *read_cnt,
+		   const uint32_t *big_list, uint32_t n_big);
+
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
 __host__ __device__ inline int pident_hundredths(int matches, int length)
 {

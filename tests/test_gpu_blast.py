@@ -191,3 +191,53 @@ def test_long_queries_ambiguity_codes_and_heavy_reads(pg, oracle_bin, tmp_path, 
     assert _blast_text(pg, db, rd, tmp_path, "rep") == want.read_bytes()
     monkeypatch.setenv("PGX_INDEX_BITS", "32")
     assert _blast_text(pg, db, rd, tmp_path, "rep32") == want.read_bytes()
+
+
+def test_very_long_query_and_thousands_of_hits(pg, oracle_bin, tmp_path):
+    """(a) one query longer than 65 535 bases sends the whole batch, short reads included, through the
+    segmented-sort ordering (the packed LDS keys hold 16-bit query coordinates); (b) reads that hit 3 000
+    subjects each: ordering and the 500-subject cut must not depend on a per-read size limit."""
+    import random
+    rng = random.Random(77)
+    big = "".join(rng.choice("ACGT") for _ in range(70000))
+    others = ["".join(rng.choice("ACGT") for _ in range(900)) for _ in range(30)]
+    db = tmp_path / "long.fa"
+    db.write_text(">gi|1|x|big|\n%s\n" % big + "".join(">gi|%d|x|s%d|\n%s\n" % (i + 2, i, s) for i, s in enumerate(others)))
+    q = list(big[1500:1500 + 66000])
+    for p_ in rng.sample(range(len(q)), 400):
+        q[p_] = rng.choice([b for b in "ACGT" if b != q[p_]])
+    reads = [">longq\n%s\n" % "".join(q)]
+    for i in range(40):
+        s = others[i % len(others)]
+        o = rng.randrange(0, 900 - 150)
+        reads.append(">s%d\n%s\n" % (i, s[o:o + 150]))
+    rd = tmp_path / "long_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "long_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)], timeout=600)[0] == 0
+    assert len(want.read_bytes()) > 2000 and b"longq\t" in want.read_bytes()
+    assert _blast_text(pg, db, rd, tmp_path, "long") == want.read_bytes()
+
+    base = "".join(rng.choice("ACGT") for _ in range(300))
+    seqs = []
+    for i in range(3000):
+        s = list(base)
+        for p_ in rng.sample(range(300), 3):
+            s[p_] = rng.choice("ACGT")
+        seqs.append("".join(s))
+    db2 = tmp_path / "many.fa"
+    db2.write_text("".join(">gi|%d|x|m%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    reads = []
+    for i in range(12):
+        o = rng.randrange(0, 300 - 150)
+        w = list(rng.choice(seqs)[o:o + 150])
+        for p_ in rng.sample(range(150), 2):
+            w[p_] = rng.choice("ACGT")
+        reads.append(">m%d\n%s\n" % (i, "".join(w)))
+    rd2 = tmp_path / "many_reads.fa"
+    rd2.write_text("".join(reads))
+    want2 = tmp_path / "many_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd2), "-db", str(db2), "-outfmt", "6", "-out", str(want2)], timeout=600)[0] == 0
+    lines = want2.read_bytes().decode().splitlines()
+    assert len({l.split("\t")[1] for l in lines if l.startswith("m0\t")}) == 500
+    assert _blast_text(pg, db2, rd2, tmp_path, "many") == want2.read_bytes()
