@@ -316,6 +316,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
 
+constexpr int kDiagSlots = 128;       // open-addressed set of (diagonal, strand) keys per read
+constexpr int kDiagProbes = 8;
+constexpr uint32_t kNoDiag = 0xFFFFFFFFu;
+
 struct WaveLds {
 	// one read per wave: kStage full records.  Two reads per wave (reads of <= 192 bases): kStage 16-byte
 	// records per read in the same bytes: subject, sstart, qstart | qend << 16 | minus << 31, score | mismatch << 16
@@ -323,8 +327,10 @@ struct WaveLds {
 		pgx_hit hit[kStage];
 		uint4 chit[2 * kStage];
 	};
-	// queued candidates: posting, strand << 31 | tested << 30 | qpos, and the subject found while filtering
+	// queued candidates: posting, strand << 31 | tested << 30 | read slot << 29 | owns-diagonal << 28 | qpos, and the
+	// subject found while filtering
 	uint32_t qp[kQueue], qmeta[kQueue], qsubj[kQueue], qs0[kQueue], qs1[kQueue];
+	uint32_t diag[2][kDiagSlots];        // per read of the pair: diagonals already owned by a queued candidate
 	unsigned int n[2];                   // staged hits per read slot
 	unsigned int direct[2];              // hits that found the stage full and went straight to the overflow table
 };
@@ -383,8 +389,8 @@ __device__ __forceinline__ void emit_hit(WaveLds *st, int rs, const OutView &ov,
 // this probe is the left-most one of its exact run (test 1 below).
 template <bool AMB, class Mask, class Emit>
 __device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read,
-						   int strand, int qp, uint32_t p, bool tested, uint32_t s, uint32_t s_start,
-						   uint32_t s_end, Emit &emit, unsigned long long &n_runs)
+						   int strand, int qp, uint32_t p, bool tested, bool claimed, uint32_t s,
+						   uint32_t s_start, uint32_t s_end, Emit &emit, unsigned long long &n_runs)
 {
 	if (p + (uint32_t)kSeedK > s_end)
 		return; // seed straddles two subjects
@@ -404,38 +410,55 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		return;
 	}
 
-	// (1) only the left-most probe inside an exact run reports that run
-	const int lm = M.last_lt(qp);
-	if (!tested && qp >= kProbeStride && lm < qp - kProbeStride)
-		return;
-	// (2) the probe 16-mer itself must match (bucket collisions, ambiguity, boundaries)
-	const int re = M.first_ge(qp);
-	if (re < qp + kSeedK)
-		return;
-	const int run_start = lm + 1;
-	if (re - run_start < kWord)
-		return;
-	n_runs++; // a >= 28 exact run reached through its left-most probe
-	if (db.dbg_stop == 5)
-		return;
-	// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
-	int pos;
+	int pos, run_start;
 	typename Mask::Win W;
-	if constexpr (Mask::kHasWindows) {
-		W = M.seed_windows();
-		if (Mask::win_any_below(W, run_start))
+	bool whole = false;
+	if constexpr (Mask::kHasWindows)
+		whole = claimed;
+	if (whole) {
+		// this candidate owns its diagonal (claimed in the dealing stage, see k_seed_extend): every >= 28 run of
+		// the diagonal is taken from the window bitmap, whichever probe got here first
+		if constexpr (Mask::kHasWindows) {
+			W = M.seed_windows();
+			run_start = Mask::win_first_ge(W, 0);
+		}
+		if (run_start >= D.hi)
+			return; // no exact run of 28 on this diagonal (the dealing-stage filter only bounds it)
+		n_runs++;
+		if (db.dbg_stop == 5 || db.dbg_stop == 6)
 			return;
 	} else {
-		pos = D.lo;
-		while (pos < run_start) {
-			int m1 = M.first_ge(pos);
-			if (m1 - pos >= kWord)
+		// (1) only the left-most probe inside an exact run reports that run
+		const int lm = M.last_lt(qp);
+		if (!tested && qp >= kProbeStride && lm < qp - kProbeStride)
+			return;
+		// (2) the probe 16-mer itself must match (bucket collisions, ambiguity, boundaries)
+		const int re = M.first_ge(qp);
+		if (re < qp + kSeedK)
+			return;
+		run_start = lm + 1;
+		if (re - run_start < kWord)
+			return;
+		n_runs++; // a >= 28 exact run reached through its left-most probe
+		if (db.dbg_stop == 5)
+			return;
+		// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
+		if constexpr (Mask::kHasWindows) {
+			W = M.seed_windows();
+			if (Mask::win_any_below(W, run_start))
 				return;
-			pos = m1 + 1;
+		} else {
+			pos = D.lo;
+			while (pos < run_start) {
+				int m1 = M.first_ge(pos);
+				if (m1 - pos >= kWord)
+					return;
+				pos = m1 + 1;
+			}
 		}
+		if (db.dbg_stop == 6)
+			return;
 	}
-	if (db.dbg_stop == 6)
-		return;
 	// (4) spec S3: seeds left to right, X-drop extension on the mismatch flags
 	int covered = D.lo;
 	pos = run_start;
@@ -576,6 +599,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 			st->n[0] = st->n[1] = 0;
 			st->direct[0] = st->direct[1] = 0;
 		}
+		if (RPW == 2) {
+#pragma unroll
+			for (int k = 0; k < 2 * kDiagSlots / 64; k++)
+				(&st->diag[0][0])[k * 64 + lane] = kNoDiag;
+		}
 		lds_fence();
 
 		// spill one read's staged hits to the overflow table in the middle of the work: it becomes fragmented
@@ -606,8 +634,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 			if ((unsigned)lane < cnt && db.dbg_stop != 3) {
 				const uint32_t p = st->qp[q_n + lane], meta = st->qmeta[q_n + lane];
 				const uint32_t sj = st->qsubj[q_n + lane], s0 = st->qs0[q_n + lane], s1 = st->qs1[q_n + lane];
-				const int strand = (int)(meta >> 31), rs = (int)((meta >> 29) & 1), qp = (int)(meta & 0x1FFFFFFFu);
-				const bool tested = (meta >> 30) & 1;
+				const int strand = (int)(meta >> 31), rs = (int)((meta >> 29) & 1), qp = (int)(meta & 0x0FFFFFFFu);
+				const bool tested = (meta >> 30) & 1, claimed = (meta >> 28) & 1;
 				const uint32_t cw0 = rs ? wB : wA, cr = rs ? rB : rA;
 				const int cL = rs ? LB : LA;
 				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + cw0;
@@ -618,9 +646,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				}
 				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh); };
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 				else
-					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 			}
 			lds_fence();
 			// a read's stage more than half full in the middle of the work: the read becomes fragmented
@@ -758,6 +786,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						}
 					}
 				}
+				// stage 5 (two short reads per wave): one candidate per diagonal.  The first survivor of a
+				// (read, strand, diagonal) enters the set and will take ALL exact runs of the diagonal from its
+				// window bitmap; later survivors of the same diagonal (one per further >= 28 run) are dropped
+				// here, before any flag build.  A diagonal that leaves its subject inside the read's span, or a
+				// full probe window of the set, falls back to the left-most-probe-of-the-first-run rule, which
+				// needs no bookkeeping; the two rules never mix on one diagonal (a key that is absent once the
+				// window is full was never inserted), so each diagonal is still reported exactly once.
+				bool claimed[kDeal];
+#pragma unroll
+				for (int u = 0; u < kDeal; u++) {
+					claimed[u] = false;
+					if (RPW == 2 && keep[u]) {
+						const int64_t d0 = (int64_t)p[u] - o_qpos[u];
+						const int Lr = o_rs[u] ? LB : LA;
+						if (d0 >= (int64_t)s0[u] && d0 + Lr <= (int64_t)s1[u]) {
+							const uint32_t key = (uint32_t)d0 | ((uint32_t)o_strand[u] << 31);
+							const uint32_t h0 = (key * 0x9E3779B1u) >> 25;
+							for (int t = 0; t < kDiagProbes; t++) {
+								const uint32_t old = atomicCAS(&st->diag[o_rs[u]][(h0 + t) & (kDiagSlots - 1)], kNoDiag, key);
+								if (old == kNoDiag) {
+									claimed[u] = true;
+									break;
+								}
+								if (old == key) {
+									keep[u] = false;
+									break;
+								}
+							}
+						}
+					}
+				}
 				if (db.dbg_stop == 2) {
 					for (int u = 0; u < kDeal; u++)
 						n_runs += keep[u] + s1[u];
@@ -771,7 +830,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						const unsigned int slot = q_n + (unsigned)__popcll(km & lt_mask);
 						st->qp[slot] = p[u];
 						st->qmeta[slot] = ((uint32_t)o_strand[u] << 31) | ((uint32_t)tested[u] << 30) | ((uint32_t)o_rs[u] << 29) |
-								  (uint32_t)o_qpos[u];
+								  ((uint32_t)claimed[u] << 28) | (uint32_t)o_qpos[u];
 						st->qsubj[slot] = sj[u];
 						st->qs0[slot] = s0[u];
 						st->qs1[slot] = s1[u];
