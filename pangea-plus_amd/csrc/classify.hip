@@ -662,10 +662,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 			const int pid = pbase + my_li;
 			uint32_t cnt = 0, lo = 0;
 			int strand = 0, qpos = 0;
+			uint32_t wl = 0, wr = 0; // the read's 16 bases from 13 left of the probe, and the 16 right of it
 			if (pid < P && (my_rs == 0 || hasB)) {
 				strand = pid >= nps;
 				qpos = (pid - strand * nps) * kProbeStride;
 				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
+				if (!AMB) {
+					wl = qpos >= kProbeStride ? window16(rw, qpos - kProbeStride) : 0u;
+					wr = window16(rw, qpos + kSeedK);
+				}
 				bool ok = true;
 				if (AMB) {
 					const uint64_t *ra = strand ? rd.rc_amb : rd.fwd_amb;
@@ -689,6 +694,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 			}
 			const uint32_t excl = incl - cnt;
 			const uint32_t T = __shfl(incl, 63);
+			const uint32_t pbase_idx = lo - excl;                               // posting index of item k of this probe: pbase_idx + k
+			const uint32_t pmeta = (uint32_t)qpos | ((uint32_t)strand << 31);  // what an item needs to know of its probe
 			n_post += cnt;
 			if (db.dbg_stop == 1)
 				continue;
@@ -697,6 +704,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				bool active[kDeal], tested[kDeal], keep[kDeal];
 				uint32_t pidx[kDeal], p[kDeal], sj[kDeal], s0[kDeal], s1[kDeal];
 				int o_strand[kDeal], o_qpos[kDeal], o_rs[kDeal];
+				uint32_t o_wl[kDeal], o_wr[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					const uint32_t item = it + 64 * u + lane;
@@ -711,10 +719,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						if (cand < 64 && e <= key)
 							o = cand;
 					}
-					pidx[u] = __shfl(lo, o) + (key - __shfl(excl, o));
-					o_strand[u] = __shfl(strand, o);
-					o_qpos[u] = __shfl(qpos, o);
+					pidx[u] = __shfl(pbase_idx, o) + key;
+					const uint32_t m = __shfl(pmeta, o);
+					o_strand[u] = (int)(m >> 31);
+					o_qpos[u] = (int)(m & 0x7FFFFFFFu);
 					o_rs[u] = o / LPR;
+					o_wl[u] = __shfl(wl, o);
+					o_wr[u] = __shfl(wr, o);
 				}
 				uint32_t raw[kDeal];
 				uint2 ctx[kDeal];
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 						ctx[u] = db.post_ctx[pidx[u]];
 				}
 				// stage 2: the 13 database bases left and the 12 right of the 16-mer (post_ctx, fetched beside
-				// the posting) against the read's (L1)
+				// the posting) against the read's (extracted once per probe, handed over by its lane)
 				uint32_t xl[kDeal], xr[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
@@ -735,13 +746,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 					tested[u] = false;
 					xl[u] = xr[u] = 0;
 					if (!AMB && active[u]) {
-						const uint64_t *rwp = (o_strand[u] ? rd.rc : rd.fwd) + (o_rs[u] ? wB : wA);
 						if (o_qpos[u] >= kProbeStride) {
 							// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
 							tested[u] = !(raw[u] >> 31);
-							xl[u] = ctx[u].x ^ window16(rwp, o_qpos[u] - kProbeStride);
+							xl[u] = ctx[u].x ^ o_wl[u];
 						}
-						xr[u] = ctx[u].y ^ window16(rwp, o_qpos[u] + kSeedK);
+						xr[u] = ctx[u].y ^ o_wr[u];
 					}
 				}
 				// stage 3: la / ra = matching bases immediately left / right of the 16-mer (capped at 13 / 12,
