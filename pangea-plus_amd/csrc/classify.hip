@@ -1236,19 +1236,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			sw->a.k2[slot0 + li] = kx.k2;
 		}
 		lds_fence();
-		// rank = number of hits that precede this one (ties, which the search cannot produce, by slot)
-		uint32_t rank = 0;
+		// rank = number of hits that precede this one.  Nearly every pair differs in the first key word (best
+		// score, subject, score): count on that word alone, and compare second words only inside groups of equal
+		// first words (several HSPs of one subject with one score), which most reads do not have.
+		uint32_t rank = 0, same = 0;
 		for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
-			uint64_t a1[4], a2[4];
+			uint64_t a1[4];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
+			for (int u = 0; u < 4; u++)
 				a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
-				a2[u] = sw->a.k2[slot0 + ((j0 + u) & (G - 1))];
-			}
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
-				const uint32_t j = j0 + u;
-				const bool before = (a1[u] < kx.k1) | ((a1[u] == kx.k1) & ((a2[u] < kx.k2) | ((a2[u] == kx.k2) & (j < (uint32_t)li))));
+				const bool in = j0 + u < n;
+				rank += (in & (a1[u] < kx.k1)) ? 1u : 0u;
+				same += (in & (a1[u] == kx.k1)) ? 1u : 0u;
+			}
+		}
+		if (__ballot(mine && same > 1u)) {
+			for (uint32_t j = 0; j < nmax; j++) {
+				const uint64_t b1 = sw->a.k1[slot0 + (j & (G - 1))], b2 = sw->a.k2[slot0 + (j & (G - 1))];
+				const bool before = (b1 == kx.k1) & ((b2 < kx.k2) | ((b2 == kx.k2) & (j < (uint32_t)li)));
 				rank += (before & (j < n)) ? 1u : 0u;
 			}
 		}
