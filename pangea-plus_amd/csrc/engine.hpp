@@ -62,7 +62,10 @@ struct pgx_reads {
 	int64_t first = 0; // ordinal of read 0 within its source (names r<first+i> for synthetic reads)
 	bool synthetic = false;
 	bool has_amb = false;
-	std::vector<std::string> names; // empty for synthetic batches
+	// names of file-built batches: first word of each header, kept as (offset, length) into the file's text
+	std::string h_text;
+	std::vector<uint64_t> name_off;
+	std::vector<uint32_t> name_len;
 	std::vector<uint32_t> h_len, h_woff;
 	std::vector<uint64_t> h_fwd; // host copy of the forward strand (file-built batches only)
 	int64_t n_words = 0;

@@ -5,8 +5,10 @@
 // `2bwt-builder ref.fasta` (README.md:130); both reference tools are external/closed, the
 // format here is the build's own.
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <chrono>
 
 #include "bitops.hpp"
 #include "engine.hpp"
@@ -748,56 +750,268 @@ static int reads_finish(pgx_reads *rd)
 
 // FASTA -> read batch. fold_to_g: every non-ACGT letter is read as G (what the reference's soap does,
 // observed) and `amb_count[i]` receives how many letters of read i were folded.
+// ------------------------------------------------------------------------------------------ FASTA text on the device
+// The read file is uploaded as it is; lines, records, letters and names are found by kernels (the host never
+// walks the text).  Same rules as split_fasta_text: a record starts at a line whose first byte is '>', lines
+// before the first record are skipped, a trailing CR is dropped, blanks and tabs inside sequence lines are
+// dropped, every other byte of a sequence line is a letter.  Files of 4 GiB and more take the host splitter.
+__global__ void k_fa_line_flags(const unsigned char *__restrict__ text, uint32_t n, uint8_t *__restrict__ flag)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		flag[i] = i == 0 || text[i - 1] == '\n';
+}
+
+__global__ void k_fa_line_starts(const uint8_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n,
+				 uint32_t *__restrict__ line_start)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flag[i])
+		line_start[idx[i]] = i;
+}
+
+// per line: is it a header, how many letters it holds, and (headers) where the name's first word ends
+__global__ void k_fa_line_info(const unsigned char *__restrict__ text, const uint32_t *__restrict__ line_start, uint32_t n_lines,
+			       uint32_t *__restrict__ hdr, uint32_t *__restrict__ nlet, uint32_t *__restrict__ name_len)
+{
+	const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+	if (l >= n_lines)
+		return;
+	const uint32_t s = line_start[l];
+	uint32_t e = line_start[l + 1];
+	if (e > s && text[e - 1] == '\n')
+		e--;
+	if (e > s && text[e - 1] == '\r')
+		e--;
+	const bool h = e > s && text[s] == '>';
+	uint32_t c = 0, nl = 0;
+	if (h) {
+		uint32_t k = s + 1;
+		while (k < e && text[k] != ' ' && text[k] != '\t')
+			k++;
+		nl = k - (s + 1);
+	} else {
+		for (uint32_t k = s; k < e; k++)
+			c += text[k] != ' ' && text[k] != '\t';
+	}
+	hdr[l] = h ? 1u : 0u;
+	nlet[l] = c;
+	name_len[l] = nl;
+}
+
+// letters of lines in front of the first record do not count
+__global__ void k_fa_drop_preamble(const uint32_t *__restrict__ rec_incl, uint32_t n_lines, uint32_t *__restrict__ nlet)
+{
+	const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+	if (l < n_lines && rec_incl[l] == 0)
+		nlet[l] = 0;
+}
+
+__global__ void k_fa_copy_letters(const unsigned char *__restrict__ text, const uint32_t *__restrict__ line_start,
+				  const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ nlet,
+				  const uint32_t *__restrict__ let_off, const uint32_t *__restrict__ rec_incl,
+				  const uint32_t *__restrict__ name_len, uint32_t n_lines, unsigned char *__restrict__ letters,
+				  uint32_t *__restrict__ rec_let_off, uint32_t *__restrict__ rec_name_off, uint32_t *__restrict__ rec_name_len)
+{
+	const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+	if (l >= n_lines)
+		return;
+	const uint32_t s = line_start[l];
+	if (hdr[l]) {
+		const uint32_t r = rec_incl[l] - 1;
+		rec_let_off[r] = let_off[l];
+		rec_name_off[r] = s + 1;
+		rec_name_len[r] = name_len[l];
+		return;
+	}
+	uint32_t left = nlet[l], o = let_off[l];
+	for (uint32_t k = s; left; k++) {
+		const unsigned char c = text[k];
+		if (c != ' ' && c != '\t') {
+			letters[o++] = c;
+			left--;
+		}
+	}
+}
+
+struct DeviceFasta {
+	DevBuf<unsigned char> d_letters;
+	std::vector<uint32_t> let_off;            // n_rec + 1 letter offsets
+	std::vector<uint32_t> name_off, name_len; // first word of each header, in the host text
+};
+
+static int u32_scan(const uint32_t *in, uint32_t *out, size_t n, bool inclusive)
+{
+	size_t bytes = 0;
+	if (inclusive)
+		PGX_HIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<uint32_t>()));
+	else
+		PGX_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>()));
+	DevBuf<uint8_t> tmp;
+	PGX_TRY(tmp.alloc(bytes ? bytes : 1));
+	if (inclusive)
+		PGX_HIP(rocprim::inclusive_scan(tmp.data(), bytes, in, out, n, rocprim::plus<uint32_t>()));
+	else
+		PGX_HIP(rocprim::exclusive_scan(tmp.data(), bytes, in, out, 0u, n, rocprim::plus<uint32_t>()));
+	return 0;
+}
+
+static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out)
+{
+	const uint32_t n = (uint32_t)n_bytes;
+	out.let_off.assign(1, 0);
+	if (n == 0)
+		return out.d_letters.alloc(1);
+	DevBuf<unsigned char> d_text;
+	DevBuf<uint8_t> d_flag;
+	DevBuf<uint32_t> d_idx;
+	PGX_TRY(d_text.alloc(n));
+	PGX_TRY(d_text.upload((const unsigned char *)text, n));
+	PGX_TRY(d_flag.alloc(n));
+	PGX_TRY(d_idx.alloc(n));
+	const unsigned gb = (n + 255) / 256;
+	hipLaunchKernelGGL(k_fa_line_flags, dim3(gb), dim3(256), 0, 0, d_text.data(), n, d_flag.data());
+	{
+		size_t bytes = 0;
+		PGX_HIP(rocprim::exclusive_scan(nullptr, bytes, d_flag.data(), d_idx.data(), 0u, (size_t)n, rocprim::plus<uint32_t>()));
+		DevBuf<uint8_t> tmp;
+		PGX_TRY(tmp.alloc(bytes ? bytes : 1));
+		PGX_HIP(rocprim::exclusive_scan(tmp.data(), bytes, d_flag.data(), d_idx.data(), 0u, (size_t)n, rocprim::plus<uint32_t>()));
+	}
+	uint32_t last_idx = 0;
+	uint8_t last_flag = 0;
+	PGX_TRY(d_idx.download(&last_idx, 1, n - 1));
+	PGX_TRY(d_flag.download(&last_flag, 1, n - 1));
+	const uint32_t n_lines = last_idx + last_flag;
+	DevBuf<uint32_t> d_line_start, d_hdr, d_nlet, d_name_len, d_rec_incl, d_let_off;
+	PGX_TRY(d_line_start.alloc((size_t)n_lines + 1));
+	PGX_TRY(d_hdr.alloc((size_t)n_lines + 1, 0, 0, true));
+	PGX_TRY(d_nlet.alloc((size_t)n_lines + 1, 0, 0, true));
+	PGX_TRY(d_name_len.alloc((size_t)n_lines + 1));
+	PGX_TRY(d_rec_incl.alloc((size_t)n_lines + 1));
+	PGX_TRY(d_let_off.alloc((size_t)n_lines + 1));
+	hipLaunchKernelGGL(k_fa_line_starts, dim3(gb), dim3(256), 0, 0, d_flag.data(), d_idx.data(), n, d_line_start.data());
+	PGX_HIP(hipMemcpy(d_line_start.data() + n_lines, &n, sizeof n, hipMemcpyHostToDevice)); // sentinel: end of the last line
+	d_flag.release();
+	d_idx.release();
+	const unsigned gl = (n_lines + 255) / 256;
+	hipLaunchKernelGGL(k_fa_line_info, dim3(gl), dim3(256), 0, 0, d_text.data(), d_line_start.data(), n_lines, d_hdr.data(),
+			   d_nlet.data(), d_name_len.data());
+	PGX_HIP(hipGetLastError());
+	PGX_TRY(u32_scan(d_hdr.data(), d_rec_incl.data(), (size_t)n_lines + 1, true));
+	hipLaunchKernelGGL(k_fa_drop_preamble, dim3(gl), dim3(256), 0, 0, d_rec_incl.data(), n_lines, d_nlet.data());
+	PGX_TRY(u32_scan(d_nlet.data(), d_let_off.data(), (size_t)n_lines + 1, false));
+	uint32_t n_rec = 0, n_let = 0;
+	PGX_TRY(d_rec_incl.download(&n_rec, 1, n_lines));
+	PGX_TRY(d_let_off.download(&n_let, 1, n_lines));
+	DevBuf<uint32_t> d_rlo, d_rno, d_rnl;
+	PGX_TRY(d_rlo.alloc((size_t)n_rec + 1));
+	PGX_TRY(d_rno.alloc((size_t)n_rec + 1));
+	PGX_TRY(d_rnl.alloc((size_t)n_rec + 1));
+	PGX_TRY(out.d_letters.alloc(n_let ? n_let : 1));
+	hipLaunchKernelGGL(k_fa_copy_letters, dim3(gl), dim3(256), 0, 0, d_text.data(), d_line_start.data(), d_hdr.data(), d_nlet.data(),
+			   d_let_off.data(), d_rec_incl.data(), d_name_len.data(), n_lines, out.d_letters.data(), d_rlo.data(), d_rno.data(),
+			   d_rnl.data());
+	PGX_HIP(hipGetLastError());
+	out.let_off.resize((size_t)n_rec + 1);
+	out.name_off.resize(n_rec);
+	out.name_len.resize(n_rec);
+	PGX_TRY(d_rlo.download(out.let_off.data(), n_rec));
+	out.let_off[n_rec] = n_let;
+	PGX_TRY(d_rno.download(out.name_off.data(), n_rec));
+	PGX_TRY(d_rnl.download(out.name_len.data(), n_rec));
+	return 0;
+}
+
 int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
 			pgx_reads **out)
 {
 	if (!path || !out)
 		return fail(PGX_E_ARG, "pgx_reads_from_fasta: null argument");
 	PGX_TRY(require_device());
+	const bool trace = getenv("PGX_TRACE") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
+	const auto t_begin = now();
 	bool ok;
 	std::string text = read_text_file(path, &ok);
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open query file %s", path);
+	const auto t_read = now();
+	// records, letters and names: found on the device for files under 4 GiB, by the host splitter otherwise
+	DeviceFasta df;
+	std::vector<uint64_t> rec_off; // n_rec + 1 letter offsets
+	pgx_reads *rd = new pgx_reads();
 	FastaLetters fl;
-	split_fasta_text(text, fl);
-	text.clear();
-	text.shrink_to_fit();
-	int64_t total = (int64_t)fl.headers.size();
+	const bool on_device = text.size() < (1ull << 32) - 2;
+	if (on_device) {
+		int rc0 = fasta_split_device(text.data(), text.size(), df);
+		if (rc0 < 0) {
+			delete rd;
+			return rc0;
+		}
+		rec_off.assign(df.let_off.begin(), df.let_off.end());
+	} else {
+		split_fasta_text(text, fl);
+		rec_off = fl.off;
+	}
+	const auto t_split = now();
+	int64_t total = (int64_t)rec_off.size() - 1;
 	if (first < 0)
 		first = 0;
 	if (first > total)
 		first = total;
 	if (count < 0 || first + count > total)
 		count = total - first;
-	pgx_reads *rd = new pgx_reads();
 	rd->n = count;
 	rd->first = first;
 	rd->h_len.resize((size_t)count);
 	rd->h_woff.resize((size_t)count + 1);
 	uint64_t nw = 0;
-	rd->names.reserve((size_t)count);
+	rd->name_off.resize((size_t)count);
+	rd->name_len.resize((size_t)count);
+	if (!on_device)
+		rd->h_text.clear();
 	for (int64_t i = 0; i < count; i++) {
-		uint64_t L = fl.off[(size_t)(first + i) + 1] - fl.off[(size_t)(first + i)];
+		uint64_t L = rec_off[(size_t)(first + i) + 1] - rec_off[(size_t)(first + i)];
 		rd->h_len[(size_t)i] = (uint32_t)L;
 		rd->h_woff[(size_t)i] = (uint32_t)nw;
 		nw += (L + 31) / 32;
 		if ((int32_t)L > rd->max_len)
 			rd->max_len = (int32_t)L;
-		rd->names.push_back(first_word(fl.headers[(size_t)(first + i)]));
+		if (on_device) {
+			rd->name_off[(size_t)i] = df.name_off[(size_t)(first + i)];
+			rd->name_len[(size_t)i] = df.name_len[(size_t)(first + i)];
+		} else {
+			const std::string nm = first_word(fl.headers[(size_t)(first + i)]);
+			rd->name_off[(size_t)i] = rd->h_text.size();
+			rd->name_len[(size_t)i] = (uint32_t)nm.size();
+			rd->h_text += nm;
+		}
 	}
 	rd->h_woff[(size_t)count] = (uint32_t)nw;
 	rd->n_words = (int64_t)nw;
-	// letters of the selected block go to the device as they are; the packing is a kernel
-	const uint64_t l0 = fl.off[(size_t)first], l1 = fl.off[(size_t)(first + count)];
+	// letters of the selected block are packed by a kernel
+	const uint64_t l0 = rec_off[(size_t)first], l1 = rec_off[(size_t)(first + count)];
 	std::vector<uint64_t> loff((size_t)count + 1);
 	for (int64_t i = 0; i <= count; i++)
-		loff[(size_t)i] = fl.off[(size_t)(first + i)] - l0;
-	DevBuf<unsigned char> d_letters;
+		loff[(size_t)i] = rec_off[(size_t)(first + i)] - l0;
+	DevBuf<unsigned char> d_letters_host;
+	int rc = 0;
+	const unsigned char *d_letters_ptr = nullptr;
+	if (on_device) {
+		d_letters_ptr = df.d_letters.data() + l0;
+		rd->h_text = std::move(text); // names are read from the text on demand
+	} else {
+		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1);
+		if (rc == 0) rc = d_letters_host.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
+		d_letters_ptr = d_letters_host.data();
+	}
 	DevBuf<uint64_t> d_loff;
 	DevBuf<uint32_t> d_namb;
 	DevBuf<unsigned int> d_flag;
-	int rc = d_letters.alloc(l1 - l0 ? l1 - l0 : 1);
-	if (rc == 0) rc = d_letters.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
 	if (rc == 0) rc = d_loff.alloc((size_t)count + 1);
 	if (rc == 0) rc = d_loff.upload(loff.data(), loff.size());
 	if (rc == 0) rc = d_namb.alloc(count ? (size_t)count : 1);
@@ -807,7 +1021,7 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	if (rc == 0) rc = rd->d_fwd.alloc((size_t)nw + 8, 0, 0, true);
 	if (rc == 0 && !fold_to_g) rc = rd->d_fwd_amb.alloc((size_t)nw + 8, 0, 0, true);
 	if (rc == 0 && count > 0) {
-		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, 0, d_letters.data(), d_loff.data(),
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, 0, d_letters_ptr, d_loff.data(),
 				   rd->d_woff.data(), (uint64_t)count, fold_to_g ? 1 : 0, rd->d_fwd.data(),
 				   fold_to_g ? (uint64_t *)nullptr : rd->d_fwd_amb.data(), d_namb.data(), d_flag.data());
 		if (hipGetLastError() != hipSuccess)
@@ -827,11 +1041,17 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 		rd->h_fwd.assign(nw + 2, 0);
 		rc = rd->d_fwd.download(rd->h_fwd.data(), (size_t)nw);
 	}
+	const auto t_pack = now();
 	if (rc == 0)
 		rc = reads_finish(rd);
 	if (rc < 0) {
 		delete rd;
 		return rc;
+	}
+	if (trace) {
+		(void)hipDeviceSynchronize();
+		fprintf(stderr, "[pgx trace] reads_from_fasta: file %.1f ms, split %.1f ms, tables+pack %.1f ms, strands %.1f ms\n",
+			ms(t_begin, t_read), ms(t_read, t_split), ms(t_split, t_pack), ms(t_pack, now()));
 	}
 	*out = rd;
 	return 0;
@@ -888,7 +1108,7 @@ std::string pgx_reads::name_of(int64_t i) const
 {
 	if (synthetic)
 		return "r" + std::to_string(first + i);
-	return names[(size_t)i];
+	return h_text.substr(name_off[(size_t)i], name_len[(size_t)i]);
 }
 
 using namespace pgx;

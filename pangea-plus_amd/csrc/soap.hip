@@ -419,12 +419,12 @@ int pgx_soap_run(const pgx_soap_opts *o)
 				if (nb > 0 && !(o->repeat_mode == 0 && nb > 1)) {
 					const size_t lim = o->repeat_mode == 2 ? he - hp : 1;
 					for (size_t x = 0; x < lim && hp + x < he; x++)
-						soap_row(out, rd->names[r], (hv[hp + x].strand_nmis >> 8) ? rv : fw, hv[hp + x], nb, db,
+						soap_row(out, rd->name_of(r), (hv[hp + x].strand_nmis >> 8) ? rv : fw, hv[hp + x], nb, db,
 							 o->repeat_mode);
 					printed = true;
 				}
 				if (!printed && nb <= 1) {
-					unm += ">" + rd->names[r] + "\n";
+					unm += ">" + rd->name_of(r) + "\n";
 					for (int k = 0; k < L; k++)
 						unm += kLetters[fw[(size_t)k]];
 					unm += "\n";

@@ -40,3 +40,53 @@ def test_imported_database_answers_identically():
     b = _capi.blast_search(dst, reads)
     assert len(a) > 1000
     assert a.format(src, reads) == b.format(dst, reads)
+
+
+def test_fasta_is_split_on_the_device_like_the_host_rules(tmp_path):
+    """Read files are uploaded as text and split by kernels (lines, records, letters, names): CRLF, blank lines,
+    wrapped sequences, blanks inside sequence lines, text in front of the first record, empty records, no final
+    newline, header words after the name, windows (first, count)."""
+    import random
+    import pangea_plus_amd as pg
+    pg.init(0)
+    rng = random.Random(5)
+    recs, text = [], ["junk before any record\n", "ACGT\n"]
+    for i in range(300):
+        L = rng.choice([0, 1, 31, 32, 33, 64, 150, 150, 150, 400])
+        seq = "".join(rng.choice("ACGTNacgtRY") for _ in range(L))
+        name = "read%d" % i
+        eol = "\r\n" if i % 3 == 0 else "\n"
+        text.append(">" + name + (" extra words\there" if i % 4 == 0 else "") + eol)
+        body = seq
+        if i % 5 == 0 and L > 40:      # wrapped at 60 with blanks and tabs sprinkled in
+            parts = [body[k:k + 60] for k in range(0, L, 60)]
+            body = eol.join(p[:10] + " " + p[10:20] + "\t" + p[20:] for p in parts)
+        text.append(body + eol)
+        if i % 7 == 0:
+            text.append(eol)
+        recs.append((name, seq))
+    blob = "".join(text)
+    blob = blob[:-1] if blob.endswith("\n") else blob   # no final newline
+    fa = tmp_path / "messy.fa"
+    fa.write_bytes(blob.encode())
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    reads = pg.Reads.from_fasta(str(fa))
+    assert len(reads) == len(recs)
+    lib = pg.lib()
+    for i, (name, seq) in enumerate(recs):
+        got = reads.get(i)
+        want = [code.get(c.upper(), 4) for c in seq]
+        assert list(got) == want, (i, name)
+    window = pg.Reads.from_fasta(str(fa), 17, 40)
+    assert len(window) == 40
+    assert list(window.get(0)) == [code.get(c.upper(), 4) for c in recs[17][1]]
+    # names travel with the batch: they appear in the formatted hit table of a search against the reads themselves
+    db_fa = tmp_path / "db.fa"
+    db_fa.write_text("".join(">gi|%d|x|%s|\n%s\n" % (i + 1, n_, s) for i, (n_, s) in enumerate(recs) if len(s) >= 150 and "N" not in s.upper()
+                             and "R" not in s.upper() and "Y" not in s.upper()) or ">gi|1|x|none|\nACGT\n")
+    db = pg.Db.from_fasta(str(db_fa))
+    from pangea_plus_amd import _capi
+    hits = _capi.blast_search(db, reads)
+    rows = hits.format(db, reads).decode().splitlines()
+    names_hit = {r.split("\t")[0] for r in rows}
+    assert names_hit <= {n_ for n_, _ in recs}
