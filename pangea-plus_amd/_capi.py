@@ -146,7 +146,10 @@ def _take_text(ptr, length=None):
     """malloc'd C string -> bytes, then pgx_free."""
     if not ptr:
         return b""
-    data = C.string_at(ptr, length) if length is not None else C.string_at(ptr)
+    if length is not None and length >= (1 << 31):  # ctypes.string_at takes a C int
+        data = bytes((C.c_char * length).from_address(ptr))
+    else:
+        data = C.string_at(ptr, length) if length is not None else C.string_at(ptr)
     lib().pgx_free(ptr)
     return data
 

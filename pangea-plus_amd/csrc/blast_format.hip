@@ -2,7 +2,10 @@
 // (12 tab-separated columns qseqid sseqid pident length mismatch gapopen qstart qend sstart send
 // evalue bitscore — the layout the reference's downstream tools parse: Megaclust/megaclust2.pl:84-96,
 // NCBI-taxcollector-0.01.pl:75-77), plus the `blastn` entry point (reference README.md:96).
+#include <rocprim/device/device_scan.hpp>
+
 #include <cmath>
+#include <functional>
 
 #include "engine.hpp"
 
@@ -137,7 +140,8 @@ void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_ns
 	bits = bs;
 }
 
-int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)
+// host rendering, one snprintf per column: kept for batches whose (read length x score) table would be huge
+static int format_hits_text_host(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)
 {
 	std::vector<pgx_hit> hv((size_t)h->n_hits);
 	std::vector<uint32_t> off((size_t)h->n_reads + 1), cnt((size_t)h->n_reads + 1);
@@ -159,6 +163,260 @@ int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads
 		}
 	}
 	return 0;
+}
+
+// ------------------------------------------------------------------------------------------ -outfmt 6 on the device
+// A search of 10 M reads yields ~280 M rows, 20 GB of text: the table is rendered by kernels.  Everything in a
+// row is an integer, a name, or a function of (raw score, query length): the e-value and bit-score columns
+// come from a host-made table of their printed texts per (length, score), pident is hundredths / 100 (exactly
+// what "%.2f" prints, engine.hpp), the rest is decimal integers.  Pass 1 sizes the rows, a scan places them,
+// pass 2 writes them; chunks of rows go to the host as they are ready.
+struct FmtView {
+	const pgx_hit *hits;
+	const uint32_t *read_off, *read_cnt, *read_len;
+	const unsigned char *name_blob; // read names back to back (null: synthetic names r<first + i>)
+	const uint32_t *name_off;
+	unsigned long long first;
+	const unsigned char *id_blob; // subject ids back to back
+	const uint32_t *id_off;
+	const uint32_t *len_slot;  // read length -> slot of the score table (or ~0)
+	const uint32_t *slot_base; // slot -> first entry of its scores
+	const uint32_t *score_off; // entry -> offset of "evalue\tbitscore" in score_blob; entry + 1 ends it
+	const unsigned char *score_blob;
+};
+
+__device__ __forceinline__ uint32_t dec_len(unsigned long long v)
+{
+	uint32_t n = 1;
+	while (v >= 10ull) {
+		v /= 10ull;
+		n++;
+	}
+	return n;
+}
+__device__ __forceinline__ unsigned char *put_dec(unsigned char *p, unsigned long long v)
+{
+	const uint32_t n = dec_len(v);
+	for (uint32_t k = n; k-- > 0;) {
+		p[k] = (unsigned char)('0' + (uint32_t)(v % 10ull));
+		v /= 10ull;
+	}
+	return p + n;
+}
+__device__ __forceinline__ unsigned char *put_bytes(unsigned char *p, const unsigned char *s, uint32_t n)
+{
+	for (uint32_t k = 0; k < n; k++)
+		p[k] = s[k];
+	return p + n;
+}
+
+// WRITE = false: row lengths; WRITE = true: the rows at their offsets
+template <bool WRITE>
+__global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long long *__restrict__ len_or_off,
+			   unsigned char *__restrict__ out)
+{
+	const uint64_t j = j0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= j1)
+		return;
+	const pgx_hit h = v.hits[j];
+	const uint32_t r = (uint32_t)h.read;
+	const bool valid = j - v.read_off[r] < v.read_cnt[r]; // slots past the 500-subject cut print nothing
+	if (!WRITE && !valid) {
+		len_or_off[j - j0] = 0;
+		return;
+	}
+	if (WRITE && !valid)
+		return;
+	const int alen = h.qend - h.qstart + 1;
+	const int hund = pident_hundredths(alen - h.mismatch, alen);
+	const uint32_t qlen = v.read_len[r];
+	const uint32_t e = v.slot_base[v.len_slot[qlen]] + (uint32_t)h.score;
+	const uint32_t so = v.score_off[e], sn = v.score_off[e + 1] - so;
+	const uint32_t io = v.id_off[h.subject], in = v.id_off[h.subject + 1] - io;
+	uint32_t no = 0, nn = 0;
+	if (v.name_blob) {
+		no = v.name_off[r];
+		nn = v.name_off[r + 1] - no;
+	} else {
+		nn = 1 + dec_len(v.first + r);
+	}
+	if (!WRITE) {
+		len_or_off[j - j0] = (unsigned long long)nn + in + (dec_len((unsigned long long)(hund / 100)) + 3) + dec_len((unsigned long long)alen) +
+				     dec_len((unsigned long long)h.mismatch) + 1 + dec_len((unsigned long long)h.qstart) +
+				     dec_len((unsigned long long)h.qend) + dec_len((unsigned long long)h.sstart) +
+				     dec_len((unsigned long long)h.send) + sn + 10 /* tabs (the 11th is inside the score text) */ + 1 /* newline */;
+		return;
+	}
+	unsigned char *p = out + len_or_off[j - j0];
+	if (v.name_blob) {
+		p = put_bytes(p, v.name_blob + no, nn);
+	} else {
+		*p++ = 'r';
+		p = put_dec(p, v.first + r);
+	}
+	*p++ = '\t';
+	p = put_bytes(p, v.id_blob + io, in);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)(hund / 100));
+	*p++ = '.';
+	*p++ = (unsigned char)('0' + (hund % 100) / 10);
+	*p++ = (unsigned char)('0' + hund % 10);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)alen);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)h.mismatch);
+	*p++ = '\t';
+	*p++ = '0';
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)h.qstart);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)h.qend);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)h.sstart);
+	*p++ = '\t';
+	p = put_dec(p, (unsigned long long)h.send);
+	*p++ = '\t';
+	p = put_bytes(p, v.score_blob + so, sn);
+	*p++ = '\n';
+}
+
+// renders the whole table; `sink` receives consecutive pieces of text
+int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads,
+		       const std::function<int(const char *, size_t)> &sink)
+{
+	PGX_TRY(require_device());
+	const uint64_t H = (uint64_t)h->n_hits;
+	if (H == 0 || h->n_reads == 0)
+		return 0;
+	// subject ids
+	std::string id_blob;
+	std::vector<uint32_t> id_off((size_t)db->n_seq + 1, 0);
+	for (size_t i = 0; i < (size_t)db->n_seq; i++) {
+		id_blob += db->ids[i];
+		id_off[i + 1] = (uint32_t)id_blob.size();
+	}
+	// read names
+	std::string name_blob;
+	std::vector<uint32_t> name_off;
+	if (!reads->synthetic) {
+		name_off.assign((size_t)reads->n + 1, 0);
+		for (int64_t r = 0; r < reads->n; r++) {
+			name_blob.append(reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+			name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
+		}
+	}
+	// score columns per (read length, raw score)
+	const uint32_t max_len = (uint32_t)reads->max_len;
+	{
+		// a dense table: fine for sequencing reads (a few hundred lengths); a batch of long, all-different
+		// queries would need hundreds of millions of entries and is rendered by the host instead
+		std::vector<uint8_t> seen((size_t)max_len + 1, 0);
+		uint64_t entries = 0;
+		for (int64_t r = 0; r < reads->n; r++)
+			if (!seen[reads->h_len[(size_t)r]]) {
+				seen[reads->h_len[(size_t)r]] = 1;
+				entries += reads->h_len[(size_t)r] + 1;
+			}
+		if (entries > (16ull << 20)) {
+			Text t;
+			PGX_TRY(format_hits_text_host(h, db, reads, t));
+			return sink(t.s.data(), t.s.size());
+		}
+	}
+	std::vector<uint32_t> len_slot((size_t)max_len + 1, 0xFFFFFFFFu), slot_base, score_off;
+	std::string score_blob;
+	{
+		std::vector<uint8_t> seen((size_t)max_len + 1, 0);
+		for (int64_t r = 0; r < reads->n; r++)
+			seen[reads->h_len[(size_t)r]] = 1;
+		std::string ev, bs;
+		for (uint32_t L = 0; L <= max_len; L++) {
+			if (!seen[L])
+				continue;
+			len_slot[L] = (uint32_t)slot_base.size();
+			slot_base.push_back((uint32_t)score_off.size());
+			for (uint32_t sc = 0; sc <= L; sc++) {
+				score_off.push_back((uint32_t)score_blob.size());
+				format_score_columns((int)sc, L, db->n_bases, db->n_seq, ev, bs);
+				score_blob += ev;
+				score_blob += '\t';
+				score_blob += bs;
+			}
+		}
+		score_off.push_back((uint32_t)score_blob.size());
+	}
+	DevBuf<unsigned char> d_id_blob, d_name_blob, d_score_blob, d_out;
+	DevBuf<uint32_t> d_id_off, d_name_off, d_len_slot, d_slot_base, d_score_off;
+	auto up_bytes = [](DevBuf<unsigned char> &d, const std::string &s) -> int {
+		PGX_TRY(d.alloc(s.size() ? s.size() : 1));
+		return d.upload((const unsigned char *)s.data(), s.size());
+	};
+	auto up_u32 = [](DevBuf<uint32_t> &d, const std::vector<uint32_t> &v) -> int {
+		PGX_TRY(d.alloc(v.size() ? v.size() : 1));
+		return d.upload(v.data(), v.size());
+	};
+	PGX_TRY(up_bytes(d_id_blob, id_blob));
+	PGX_TRY(up_u32(d_id_off, id_off));
+	if (!reads->synthetic) {
+		PGX_TRY(up_bytes(d_name_blob, name_blob));
+		PGX_TRY(up_u32(d_name_off, name_off));
+	}
+	PGX_TRY(up_u32(d_len_slot, len_slot));
+	PGX_TRY(up_u32(d_slot_base, slot_base));
+	PGX_TRY(up_u32(d_score_off, score_off));
+	PGX_TRY(up_bytes(d_score_blob, score_blob));
+	FmtView v;
+	v.hits = h->d_hits.data();
+	v.read_off = h->d_read_off.data();
+	v.read_cnt = h->d_read_cnt.data();
+	v.read_len = reads->d_len.data();
+	v.name_blob = reads->synthetic ? nullptr : d_name_blob.data();
+	v.name_off = d_name_off.data();
+	v.first = (unsigned long long)reads->first;
+	v.id_blob = d_id_blob.data();
+	v.id_off = d_id_off.data();
+	v.len_slot = d_len_slot.data();
+	v.slot_base = d_slot_base.data();
+	v.score_off = d_score_off.data();
+	v.score_blob = d_score_blob.data();
+	const uint64_t chunk = 16ull << 20; // rows per piece (~1.2 GB of text)
+	DevBuf<unsigned long long> d_len, d_off;
+	PGX_TRY(d_len.alloc(std::min(H, chunk) + 1));
+	PGX_TRY(d_off.alloc(std::min(H, chunk) + 1));
+	size_t scan_bytes = 0;
+	PGX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_len.data(), d_off.data(), 0ull, (size_t)std::min(H, chunk) + 1,
+					rocprim::plus<unsigned long long>()));
+	DevBuf<uint8_t> scan_tmp;
+	PGX_TRY(scan_tmp.alloc(scan_bytes ? scan_bytes : 1));
+	std::vector<char> host;
+	for (uint64_t j0 = 0; j0 < H; j0 += chunk) {
+		const uint64_t j1 = std::min(H, j0 + chunk), m = j1 - j0;
+		const unsigned grid = (unsigned)((m + 255) / 256);
+		hipLaunchKernelGGL(k_fmt_rows<false>, dim3(grid), dim3(256), 0, 0, v, j0, j1, d_len.data(), (unsigned char *)nullptr);
+		PGX_HIP(hipMemsetAsync(d_len.data() + m, 0, sizeof(unsigned long long), 0));
+		PGX_HIP(rocprim::exclusive_scan(scan_tmp.data(), scan_bytes, d_len.data(), d_off.data(), 0ull, (size_t)m + 1,
+						rocprim::plus<unsigned long long>()));
+		unsigned long long bytes = 0;
+		PGX_TRY(d_off.download(&bytes, 1, (size_t)m));
+		if (bytes == 0)
+			continue;
+		if (d_out.n < bytes)
+			PGX_TRY(d_out.alloc(bytes + bytes / 8));
+		hipLaunchKernelGGL(k_fmt_rows<true>, dim3(grid), dim3(256), 0, 0, v, j0, j1, d_off.data(), d_out.data());
+		PGX_HIP(hipGetLastError());
+		host.resize(bytes);
+		PGX_HIP(hipMemcpy(host.data(), d_out.data(), bytes, hipMemcpyDeviceToHost));
+		PGX_TRY(sink(host.data(), bytes));
+	}
+	return 0;
+}
+
+int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)
+{
+	return format_hits_stream(h, db, reads, [&](const char *p, size_t n) {
+		out.s.append(p, n);
+		return 0;
+	});
 }
 
 } // namespace pgx
@@ -201,11 +459,19 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 	pgx_hits *h = nullptr;
 	if (rc == 0)
 		rc = pgx_blast_search(db, rd, &h);
-	Text t;
-	if (rc == 0)
-		rc = format_hits_text(h, db, rd, t);
-	if (rc == 0)
-		rc = write_text_file(o->out_path, t.s);
+	if (rc == 0) {
+		// the table is rendered on the device and streamed to the file piece by piece
+		FILE *fo = fopen(o->out_path, "wb");
+		if (!fo) {
+			rc = fail(PGX_E_IO, "cannot open %s for writing", o->out_path);
+		} else {
+			rc = format_hits_stream(h, db, rd, [&](const char *p, size_t n) {
+				return fwrite(p, 1, n, fo) == n ? 0 : fail(PGX_E_IO, "short write to %s", o->out_path);
+			});
+			if (fclose(fo) != 0 && rc == 0)
+				rc = fail(PGX_E_IO, "cannot close %s", o->out_path);
+		}
+	}
 	pgx_hits_close(h);
 	pgx_reads_close(rd);
 	pgx_db_close(db);
