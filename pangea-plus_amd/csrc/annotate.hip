@@ -18,6 +18,8 @@
 
 namespace pgx {
 
+bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
+			     std::string &out, int *rc_out);
 void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, Text &out);
 
 // ------------------------------------------------------------------------------------------ lineage text
@@ -710,6 +712,18 @@ int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hit
 		return fail(PGX_E_ARG, "pgx_consensus_format: null argument");
 	if (!db->bound)
 		return fail(PGX_E_ARG, "pgx_consensus_format: database is not bound to a taxonomy");
+	if (n > reads->n)
+		n = reads->n;
+	{
+		// rendered by kernels (blast_format.hip); the host loop below serves batches of long, all-different queries
+		Text dev;
+		int drc = 0;
+		if (consensus_format_device(db, reads, hits, recs, n, dev.s, &drc)) {
+			PGX_TRY(drc);
+			*text = dev.release_malloc(len);
+			return *text ? 0 : fail(PGX_E_NOMEM, "out of memory");
+		}
+	}
 	std::vector<pgx_hit> hv((size_t)hits->n_hits);
 	PGX_TRY(hits->d_hits.download(hv.data(), hv.size()));
 	Text out;

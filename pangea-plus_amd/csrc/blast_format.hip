@@ -280,6 +280,9 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 	*p++ = '\n';
 }
 
+static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, std::vector<uint32_t> &len_slot,
+			      std::vector<uint32_t> &slot_base, std::vector<uint32_t> &score_off, std::string &score_blob);
+
 // renders the whole table; `sink` receives consecutive pieces of text
 int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads,
 		       const std::function<int(const char *, size_t)> &sink)
@@ -305,45 +308,14 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 			name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 		}
 	}
-	// score columns per (read length, raw score)
-	const uint32_t max_len = (uint32_t)reads->max_len;
-	{
-		// a dense table: fine for sequencing reads (a few hundred lengths); a batch of long, all-different
-		// queries would need hundreds of millions of entries and is rendered by the host instead
-		std::vector<uint8_t> seen((size_t)max_len + 1, 0);
-		uint64_t entries = 0;
-		for (int64_t r = 0; r < reads->n; r++)
-			if (!seen[reads->h_len[(size_t)r]]) {
-				seen[reads->h_len[(size_t)r]] = 1;
-				entries += reads->h_len[(size_t)r] + 1;
-			}
-		if (entries > (16ull << 20)) {
-			Text t;
-			PGX_TRY(format_hits_text_host(h, db, reads, t));
-			return sink(t.s.data(), t.s.size());
-		}
-	}
-	std::vector<uint32_t> len_slot((size_t)max_len + 1, 0xFFFFFFFFu), slot_base, score_off;
+	// score columns per (read length, raw score): a dense table, fine for sequencing reads (a few hundred lengths); a
+	// batch of long, all-different queries would need hundreds of millions of entries and is rendered by the host
+	std::vector<uint32_t> len_slot, slot_base, score_off;
 	std::string score_blob;
-	{
-		std::vector<uint8_t> seen((size_t)max_len + 1, 0);
-		for (int64_t r = 0; r < reads->n; r++)
-			seen[reads->h_len[(size_t)r]] = 1;
-		std::string ev, bs;
-		for (uint32_t L = 0; L <= max_len; L++) {
-			if (!seen[L])
-				continue;
-			len_slot[L] = (uint32_t)slot_base.size();
-			slot_base.push_back((uint32_t)score_off.size());
-			for (uint32_t sc = 0; sc <= L; sc++) {
-				score_off.push_back((uint32_t)score_blob.size());
-				format_score_columns((int)sc, L, db->n_bases, db->n_seq, ev, bs);
-				score_blob += ev;
-				score_blob += '\t';
-				score_blob += bs;
-			}
-		}
-		score_off.push_back((uint32_t)score_blob.size());
+	if (!build_score_table(db, reads, reads->n, false, len_slot, slot_base, score_off, score_blob)) {
+		Text t;
+		PGX_TRY(format_hits_text_host(h, db, reads, t));
+		return sink(t.s.data(), t.s.size());
 	}
 	DevBuf<unsigned char> d_id_blob, d_name_blob, d_score_blob, d_out;
 	DevBuf<uint32_t> d_id_off, d_name_off, d_len_slot, d_slot_base, d_score_off;
@@ -409,6 +381,231 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 		PGX_TRY(sink(host.data(), bytes));
 	}
 	return 0;
+}
+
+// ------------------------------------------------------------------------------------------ Consensus text on the device
+// One block of text per read (Consensus:223-234): the taxcollector line of the winning hit -- id, lineage, then the
+// non-empty numeric columns (taxcollector:148-153; its split on blanks drops the blank in front of a 3-digit bit
+// score) -- and "#Matches found: N".  Same two-pass scheme as the hit table.
+struct ConsFmtView {
+	FmtView f;                    // id_blob / id_off hold the lineage texts per lineage id here
+	const pgx_consensus_rec *recs;
+	const uint32_t *subj_lin;
+};
+
+template <bool WRITE>
+__global__ void k_fmt_consensus(ConsFmtView c, uint64_t r0, uint64_t r1, unsigned long long *__restrict__ len_or_off,
+				unsigned char *__restrict__ out)
+{
+	const uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= r1)
+		return;
+	const FmtView &v = c.f;
+	const pgx_consensus_rec rec = c.recs[r];
+	if (rec.hit == -2) { // no BLAST lines for this read: the Perl prints nothing for it
+		if (!WRITE)
+			len_or_off[r - r0] = 0;
+		return;
+	}
+	const uint32_t mlen = 16 /* "#Matches found: " */ + dec_len((unsigned long long)rec.matches) + 1;
+	uint32_t row = 1; // the newline of an empty line
+	pgx_hit h;
+	int alen = 0, hund = 0;
+	uint32_t so = 0, sn = 0, io = 0, in = 0, no = 0, nn = 0;
+	if (rec.hit >= 0) {
+		h = v.hits[rec.hit];
+		alen = h.qend - h.qstart + 1;
+		hund = pident_hundredths(alen - h.mismatch, alen);
+		const uint32_t e = v.slot_base[v.len_slot[v.read_len[r]]] + (uint32_t)h.score;
+		so = v.score_off[e];
+		sn = v.score_off[e + 1] - so;
+		const uint32_t lin = c.subj_lin[h.subject];
+		io = v.id_off[lin];
+		in = v.id_off[lin + 1] - io;
+		if (v.name_blob) {
+			no = v.name_off[r];
+			nn = v.name_off[r + 1] - no;
+		} else {
+			nn = 1 + dec_len(v.first + r);
+		}
+		row = nn + in + (dec_len((unsigned long long)(hund / 100)) + 3) + dec_len((unsigned long long)alen) +
+		      dec_len((unsigned long long)h.mismatch) + 1 + dec_len((unsigned long long)h.qstart) + dec_len((unsigned long long)h.qend) +
+		      dec_len((unsigned long long)h.sstart) + dec_len((unsigned long long)h.send) + sn + 10 + 1;
+	}
+	if (!WRITE) {
+		len_or_off[r - r0] = (unsigned long long)row + mlen;
+		return;
+	}
+	unsigned char *p = out + len_or_off[r - r0];
+	if (rec.hit >= 0) {
+		if (v.name_blob) {
+			p = put_bytes(p, v.name_blob + no, nn);
+		} else {
+			*p++ = 'r';
+			p = put_dec(p, v.first + r);
+		}
+		*p++ = '\t';
+		p = put_bytes(p, v.id_blob + io, in);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)(hund / 100));
+		*p++ = '.';
+		*p++ = (unsigned char)('0' + (hund % 100) / 10);
+		*p++ = (unsigned char)('0' + hund % 10);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)alen);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)h.mismatch);
+		*p++ = '\t';
+		*p++ = '0';
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)h.qstart);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)h.qend);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)h.sstart);
+		*p++ = '\t';
+		p = put_dec(p, (unsigned long long)h.send);
+		*p++ = '\t';
+		p = put_bytes(p, v.score_blob + so, sn);
+	}
+	*p++ = '\n';
+	const char tag[] = "#Matches found: ";
+	for (int k = 0; k < 16; k++)
+		*p++ = (unsigned char)tag[k];
+	p = put_dec(p, (unsigned long long)rec.matches);
+	*p++ = '\n';
+}
+
+// score-column table shared by the two renderers; false when it would be too large (see format_hits_stream)
+static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, std::vector<uint32_t> &len_slot,
+			      std::vector<uint32_t> &slot_base, std::vector<uint32_t> &score_off, std::string &score_blob)
+{
+	const uint32_t max_len = (uint32_t)reads->max_len;
+	std::vector<uint8_t> seen((size_t)max_len + 1, 0);
+	uint64_t entries = 0;
+	for (int64_t r = 0; r < n; r++)
+		if (!seen[reads->h_len[(size_t)r]]) {
+			seen[reads->h_len[(size_t)r]] = 1;
+			entries += reads->h_len[(size_t)r] + 1;
+		}
+	if (entries > (16ull << 20))
+		return false;
+	len_slot.assign((size_t)max_len + 1, 0xFFFFFFFFu);
+	std::string ev, bs;
+	for (uint32_t L = 0; L <= max_len; L++) {
+		if (!seen[L])
+			continue;
+		len_slot[L] = (uint32_t)slot_base.size();
+		slot_base.push_back((uint32_t)score_off.size());
+		for (uint32_t sc = 0; sc <= L; sc++) {
+			score_off.push_back((uint32_t)score_blob.size());
+			format_score_columns((int)sc, L, db->n_bases, db->n_seq, ev, bs);
+			score_blob += ev;
+			score_blob += '\t';
+			size_t b0 = 0;
+			while (trim_bits && b0 < bs.size() && bs[b0] == ' ')
+				b0++;
+			score_blob.append(bs, b0, std::string::npos);
+		}
+	}
+	score_off.push_back((uint32_t)score_blob.size());
+	return true;
+}
+
+// false: not rendered (score table too large), the caller uses its host loop
+bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
+			     std::string &out, int *rc_out)
+{
+	*rc_out = 0;
+	std::vector<uint32_t> len_slot, slot_base, score_off;
+	std::string score_blob;
+	if (!build_score_table(db, reads, n, true, len_slot, slot_base, score_off, score_blob))
+		return false;
+	auto run = [&]() -> int {
+		std::string lin_blob, name_blob;
+		std::vector<uint32_t> lin_off(db->lin_text.size() + 1, 0), name_off;
+		for (size_t i = 0; i < db->lin_text.size(); i++) {
+			lin_blob += db->lin_text[i];
+			lin_off[i + 1] = (uint32_t)lin_blob.size();
+		}
+		if (!reads->synthetic) {
+			name_off.assign((size_t)n + 1, 0);
+			for (int64_t r = 0; r < n; r++) {
+				name_blob.append(reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+				name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
+			}
+		}
+		DevBuf<unsigned char> d_lin_blob, d_name_blob, d_score_blob, d_out;
+		DevBuf<uint32_t> d_lin_off, d_name_off, d_len_slot, d_slot_base, d_score_off;
+		DevBuf<pgx_consensus_rec> d_recs;
+		auto up_bytes = [](DevBuf<unsigned char> &d, const std::string &s) -> int {
+			PGX_TRY(d.alloc(s.size() ? s.size() : 1));
+			return d.upload((const unsigned char *)s.data(), s.size());
+		};
+		auto up_u32 = [](DevBuf<uint32_t> &d, const std::vector<uint32_t> &v) -> int {
+			PGX_TRY(d.alloc(v.size() ? v.size() : 1));
+			return d.upload(v.data(), v.size());
+		};
+		PGX_TRY(up_bytes(d_lin_blob, lin_blob));
+		PGX_TRY(up_u32(d_lin_off, lin_off));
+		if (!reads->synthetic) {
+			PGX_TRY(up_bytes(d_name_blob, name_blob));
+			PGX_TRY(up_u32(d_name_off, name_off));
+		}
+		PGX_TRY(up_u32(d_len_slot, len_slot));
+		PGX_TRY(up_u32(d_slot_base, slot_base));
+		PGX_TRY(up_u32(d_score_off, score_off));
+		PGX_TRY(up_bytes(d_score_blob, score_blob));
+		PGX_TRY(d_recs.alloc(n ? (size_t)n : 1));
+		PGX_TRY(d_recs.upload(recs, (size_t)n));
+		ConsFmtView c;
+		c.f.hits = hits->d_hits.data();
+		c.f.read_off = hits->d_read_off.data();
+		c.f.read_cnt = hits->d_read_cnt.data();
+		c.f.read_len = reads->d_len.data();
+		c.f.name_blob = reads->synthetic ? nullptr : d_name_blob.data();
+		c.f.name_off = d_name_off.data();
+		c.f.first = (unsigned long long)reads->first;
+		c.f.id_blob = d_lin_blob.data();
+		c.f.id_off = d_lin_off.data();
+		c.f.len_slot = d_len_slot.data();
+		c.f.slot_base = d_slot_base.data();
+		c.f.score_off = d_score_off.data();
+		c.f.score_blob = d_score_blob.data();
+		c.recs = d_recs.data();
+		c.subj_lin = db->d_subj_lin.data();
+		const uint64_t N = (uint64_t)n, chunk = 4ull << 20;
+		DevBuf<unsigned long long> d_len, d_off;
+		PGX_TRY(d_len.alloc(std::min(N, chunk) + 1));
+		PGX_TRY(d_off.alloc(std::min(N, chunk) + 1));
+		size_t scan_bytes = 0;
+		PGX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_len.data(), d_off.data(), 0ull, (size_t)std::min(N, chunk) + 1,
+						rocprim::plus<unsigned long long>()));
+		DevBuf<uint8_t> scan_tmp;
+		PGX_TRY(scan_tmp.alloc(scan_bytes ? scan_bytes : 1));
+		for (uint64_t r0 = 0; r0 < N; r0 += chunk) {
+			const uint64_t r1 = std::min(N, r0 + chunk), m = r1 - r0;
+			const unsigned grid = (unsigned)((m + 255) / 256);
+			hipLaunchKernelGGL(k_fmt_consensus<false>, dim3(grid), dim3(256), 0, 0, c, r0, r1, d_len.data(), (unsigned char *)nullptr);
+			PGX_HIP(hipMemsetAsync(d_len.data() + m, 0, sizeof(unsigned long long), 0));
+			PGX_HIP(rocprim::exclusive_scan(scan_tmp.data(), scan_bytes, d_len.data(), d_off.data(), 0ull, (size_t)m + 1,
+							rocprim::plus<unsigned long long>()));
+			unsigned long long bytes = 0;
+			PGX_TRY(d_off.download(&bytes, 1, (size_t)m));
+			if (bytes == 0)
+				continue;
+			if (d_out.n < bytes)
+				PGX_TRY(d_out.alloc(bytes + bytes / 8));
+			hipLaunchKernelGGL(k_fmt_consensus<true>, dim3(grid), dim3(256), 0, 0, c, r0, r1, d_off.data(), d_out.data());
+			PGX_HIP(hipGetLastError());
+			const size_t at = out.size();
+			out.resize(at + bytes);
+			PGX_HIP(hipMemcpy(&out[at], d_out.data(), bytes, hipMemcpyDeviceToHost));
+		}
+		return 0;
+	};
+	*rc_out = run();
+	return true;
 }
 
 int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)

@@ -60,6 +60,12 @@ def test_fused_pipeline_equals_oracle_chain(pg, chain):
     recs2 = np.zeros(N, dtype=_capi.REC_DTYPE)
     _capi._check(pg.lib().pgx_consensus_batch(db.ptr, hits.ptr, rdp2.ptr, recs2.ctypes.data, N))
     assert (recs2 == recs).all()
+    # reads handed over as a FASTA file: names come from the file's text, tables are rendered on the device
+    freads = pg.Reads.from_fasta(str(chain / "reads.fa"))
+    frdp = pg.Rdp.from_file(str(chain / "rdp.tsv"), freads, db)
+    fhits, frecs = _capi.classify_consensus(db, freads, frdp)
+    assert fhits.format(db, freads) == (chain / "hits.tsv").read_bytes()
+    assert _capi.consensus_format(db, freads, fhits, frecs) == want
 
 
 def test_file_verbs_chain_equals_oracle_chain(pg, chain, tmp_path):
