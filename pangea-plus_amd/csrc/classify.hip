@@ -29,7 +29,7 @@ struct DbView {
 	const uint64_t *words, *amb;
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
 	const uint4 *blk_info;
-	const uint2 *post_ctx;
+	const uint3 *post_ctx;
 	uint32_t n_seq;
 	int bits;
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
@@ -731,10 +731,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				uint2 ctx[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
-					raw[u] = active[u] ? db.postings[pidx[u]] : 0u;
+					raw[u] = 0u;
 					ctx[u] = make_uint2(0u, 0u);
-					if (!AMB && active[u])
-						ctx[u] = db.post_ctx[pidx[u]];
+					if (AMB) {
+						if (active[u])
+							raw[u] = db.postings[pidx[u]];
+					} else if (active[u]) {
+						// posting and its context in one 12-byte record
+						const uint3 rec = db.post_ctx[pidx[u]];
+						raw[u] = rec.x;
+						ctx[u] = make_uint2(rec.y, rec.z);
+					}
 				}
 				// stage 2: the 13 database bases left and the 12 right of the 16-mer (post_ctx, fetched beside
 				// the posting) against the read's (extracted once per probe, handed over by its lane)

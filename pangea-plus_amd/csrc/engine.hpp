@@ -31,7 +31,9 @@ struct pgx_db {
 	int index_bits = 0;
 	int64_t n_postings = 0;
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
-	pgx::DevBuf<uint2> d_post_ctx; // per posting: database bases left / right of the 16-mer (databases without ambiguity)
+	// databases without ambiguity: 12-byte records {posting, database bases left of the 16-mer, bases right of it}, the
+	// stream k_seed_extend deals from (one contiguous piece per bucket instead of two)
+	pgx::DevBuf<uint3> d_post_ctx;
 
 	// taxonomy binding (pgx_db_bind_taxonomy): per subject lineage text + consensus tokens
 	bool bound = false;

@@ -233,17 +233,18 @@ __global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, 
 	}
 }
 
-// post_ctx[i] = the database around posting i, in index order: x = the 16 bases from 13 left of the 16-mer,
-// y = the 16 bases right of it.  k_seed_extend's duplicate and short-run filters read them from this
+// post_ctx[i] = posting i with the database around it, in index order: x = the posting, y = the 16 bases from 13 left of the 16-mer,
+// z = the 16 bases right of it.  k_seed_extend's duplicate and short-run filters read them from this
 // contiguous stream instead of fetching a random database line per posting.
 __global__ void k_post_ctx(const uint64_t *__restrict__ words, const uint32_t *__restrict__ postings, uint64_t n,
-			   uint2 *__restrict__ ctx)
+			   uint3 *__restrict__ ctx)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
-		const int64_t p = (int64_t)(postings[i] & 0x7FFFFFFFu);
-		ctx[i] = make_uint2(window16(words, p - kProbeStride), window16(words, p + kSeedK));
+		const uint32_t raw = postings[i];
+		const int64_t p = (int64_t)(raw & 0x7FFFFFFFu);
+		ctx[i] = make_uint3(raw, window16(words, p - kProbeStride), window16(words, p + kSeedK));
 	}
 }
 
