@@ -241,3 +241,61 @@ def test_very_long_query_and_thousands_of_hits(pg, oracle_bin, tmp_path):
     lines = want2.read_bytes().decode().splitlines()
     assert len({l.split("\t")[1] for l in lines if l.startswith("m0\t")}) == 500
     assert _blast_text(pg, db2, rd2, tmp_path, "many") == want2.read_bytes()
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_random_mixtures_match_oracle(pg, oracle_bin, tmp_path, seed):
+    """Fuzz: databases of 40-3 000-base sequences (repeats, N runs, IUPAC letters, near-identical copies), reads of
+    20-320 bases from either strand with substitutions and Ns: short reads (< 28: no hit possible), dense (<= 192) and
+    long (> 192) reads in one batch, hits at sequence ends, reads spanning two adjacent sequences."""
+    import random
+    rng = random.Random(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "R": "Y", "Y": "R"}
+    seqs = []
+    for i in range(150):
+        L = rng.choice([40, 60, 150, 300, 700, 1500, 3000])
+        if seqs and rng.random() < 0.35:
+            s = list(rng.choice(seqs))[:L]
+            for p_ in rng.sample(range(len(s)), max(1, len(s) // 40)):
+                s[p_] = rng.choice("ACGT")
+            s = "".join(s)
+        else:
+            s = "".join(rng.choice("ACGT") for _ in range(L))
+        if rng.random() < 0.2 and L > 100:
+            a = rng.randrange(0, L - 30)
+            s = s[:a] + "N" * rng.choice([1, 3, 12]) + s[a:]
+        if rng.random() < 0.1:
+            a = rng.randrange(0, len(s))
+            s = s[:a] + rng.choice("RYKM") + s[a + 1:]
+        if rng.random() < 0.1 and L > 200:
+            a = rng.randrange(0, L - 60)
+            s = s[:a] + s[a:a + 40] * 2 + s[a:]     # tandem repeat
+        seqs.append(s)
+    db = tmp_path / "fz.fa"
+    db.write_text("".join(">gi|%d|x|f%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    cat = "".join(seqs)
+    reads = []
+    for i in range(1500):
+        L = rng.choice([20, 27, 28, 29, 40, 75, 100, 150, 150, 150, 192, 193, 250, 320])
+        if rng.random() < 0.15:
+            o = rng.randrange(0, max(1, len(cat) - L))
+            w = list(cat[o:o + L])                  # may span two adjacent database sequences
+        else:
+            s = rng.choice(seqs)
+            if len(s) < L:
+                w = list(s)
+            else:
+                o = rng.choice([0, len(s) - L, rng.randrange(0, len(s) - L + 1)])
+                w = list(s[o:o + L])
+        for p_ in rng.sample(range(len(w)), rng.choice([0, 0, 1, 2, 3, len(w) // 20])):
+            w[p_] = rng.choice("ACGTN")
+        w = "".join(w)
+        if rng.random() < 0.5:
+            w = "".join(comp.get(c, "N") for c in reversed(w))
+        reads.append(">z%d\n%s\n" % (i, w))
+    rd = tmp_path / "fz_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "fz_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)], timeout=600)[0] == 0
+    assert len(want.read_bytes()) > 50000
+    assert _blast_text(pg, db, rd, tmp_path, "fz") == want.read_bytes()
