@@ -648,29 +648,59 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 	const int64_t total = fasta_count_records(o->query_path);
 	if (total < 0)
 		rc = fail(PGX_E_IO, "cannot open query file %s", o->query_path);
-	pgx_reads *rd = nullptr;
-	if (rc == 0) {
-		int64_t lo = total * rk / ws, hi = total * (rk + 1) / ws;
-		rc = pgx_reads_from_fasta(o->query_path, lo, hi - lo, &rd);
-	}
-	pgx_hits *h = nullptr;
-	if (rc == 0)
-		rc = pgx_blast_search(db, rd, &h);
-	if (rc == 0) {
-		// the table is rendered on the device and streamed to the file piece by piece
-		FILE *fo = fopen(o->out_path, "wb");
-		if (!fo) {
-			rc = fail(PGX_E_IO, "cannot open %s for writing", o->out_path);
-		} else {
-			rc = format_hits_stream(h, db, rd, [&](const char *p, size_t n) {
-				return fwrite(p, 1, n, fo) == n ? 0 : fail(PGX_E_IO, "short write to %s", o->out_path);
-			});
-			if (fclose(fo) != 0 && rc == 0)
-				rc = fail(PGX_E_IO, "cannot close %s", o->out_path);
+	const int64_t lo = total > 0 ? total * rk / ws : 0, hi = total > 0 ? total * (rk + 1) / ws : 0;
+	FILE *fo = nullptr, *fq = nullptr;
+	if (rc == 0 && !(fo = fopen(o->out_path, "wb")))
+		rc = fail(PGX_E_IO, "cannot open %s for writing", o->out_path);
+	if (rc == 0 && !(fq = fopen(o->query_path, "rb")))
+		rc = fail(PGX_E_IO, "cannot open query file %s", o->query_path);
+	// The query file is streamed in pieces of about 1 GiB that end at a record boundary: each piece is one resident
+	// batch (split + packed on the device, searched, its table rendered on the device and appended to the output),
+	// so neither the file nor the hit table has to fit anywhere at once.
+	const size_t piece_bytes = getenv("PGX_BLASTN_PIECE") ? (size_t)atoll(getenv("PGX_BLASTN_PIECE")) : ((size_t)1 << 30);
+	std::string carry;
+	int64_t seen = 0; // records in front of the current piece
+	bool eof = false;
+	while (rc == 0 && !eof && seen < hi) {
+		std::string piece = std::move(carry);
+		carry.clear();
+		const size_t old = piece.size();
+		piece.resize(old + piece_bytes);
+		const size_t got = fread(&piece[old], 1, piece_bytes, fq);
+		piece.resize(old + got);
+		eof = got < piece_bytes;
+		if (!eof) {
+			// cut at the last record start; the rest joins the next piece
+			size_t cut = piece.rfind("\n>");
+			if (cut == std::string::npos || cut == 0) {
+				carry = std::move(piece); // one record larger than a piece: keep reading
+				continue;
+			}
+			carry.assign(piece, cut + 1, std::string::npos);
+			piece.resize(cut + 1);
 		}
+		bool bol = true;
+		const int64_t here = fasta_count_records_text(piece.data(), piece.size(), &bol);
+		const int64_t a = std::max(lo, seen), b = std::min(hi, seen + here);
+		if (a < b) {
+			pgx_reads *rd = nullptr;
+			pgx_hits *h = nullptr;
+			rc = reads_from_fasta_text(std::move(piece), a - seen, b - a, false, nullptr, &rd);
+			if (rc == 0)
+				rc = pgx_blast_search(db, rd, &h);
+			if (rc == 0)
+				rc = format_hits_stream(h, db, rd, [&](const char *p, size_t n) {
+					return fwrite(p, 1, n, fo) == n ? 0 : fail(PGX_E_IO, "short write to %s", o->out_path);
+				});
+			pgx_hits_close(h);
+			pgx_reads_close(rd);
+		}
+		seen += here;
 	}
-	pgx_hits_close(h);
-	pgx_reads_close(rd);
+	if (fq)
+		fclose(fq);
+	if (fo && fclose(fo) != 0 && rc == 0)
+		rc = fail(PGX_E_IO, "cannot close %s", o->out_path);
 	pgx_db_close(db);
 	return rc;
 }

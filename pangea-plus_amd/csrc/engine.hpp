@@ -105,6 +105,9 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);
 int db_read_host(const char *prefix, pgx_db **out);
 int64_t fasta_count_records(const char *path);
+int64_t fasta_count_records_text(const char *base, size_t len, bool *at_line_start);
+int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
+			  pgx_reads **out);
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);
 

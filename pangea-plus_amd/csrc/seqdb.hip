@@ -940,6 +940,21 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	std::string text = read_text_file(path, &ok);
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open query file %s", path);
+	if (trace)
+		fprintf(stderr, "[pgx trace] reads_from_fasta: file %.1f ms\n", ms(t_begin, now()));
+	return reads_from_fasta_text(std::move(text), first, count, fold_to_g, amb_count, out);
+}
+
+// the same for FASTA text already in memory (pgx_blastn_run streams large query files through this in pieces)
+int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
+			  pgx_reads **out)
+{
+	PGX_TRY(require_device());
+	const bool trace = getenv("PGX_TRACE") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
 	const auto t_read = now();
 	// records, letters and names: found on the device for files under 4 GiB, by the host splitter otherwise
 	DeviceFasta df;
@@ -1051,8 +1066,8 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	}
 	if (trace) {
 		(void)hipDeviceSynchronize();
-		fprintf(stderr, "[pgx trace] reads_from_fasta: file %.1f ms, split %.1f ms, tables+pack %.1f ms, strands %.1f ms\n",
-			ms(t_begin, t_read), ms(t_read, t_split), ms(t_split, t_pack), ms(t_pack, now()));
+		fprintf(stderr, "[pgx trace] reads_from_fasta: split %.1f ms, tables+pack %.1f ms, strands %.1f ms\n", ms(t_read, t_split),
+			ms(t_split, t_pack), ms(t_pack, now()));
 	}
 	*out = rd;
 	return 0;
@@ -1083,23 +1098,40 @@ int db_fold_amb_to_g(const pgx_db *src, pgx_db **out)
 int db_read_host(const char *prefix, pgx_db **out) { return db_read_file(prefix, out); }
 
 // number of FASTA records of a file (lines starting with '>'), without packing anything
-int64_t fasta_count_records(const char *path)
+// records (lines that start with '>') in a piece of FASTA text; `at_line_start` carries over between pieces
+int64_t fasta_count_records_text(const char *base, size_t len, bool *at_line_start)
 {
-	bool ok;
-	std::string text = read_text_file(path, &ok);
-	if (!ok)
-		return -1;
 	int64_t n = 0;
-	const char *base = text.data();
-	size_t i = 0, len = text.size();
+	size_t i = 0;
+	bool bol = *at_line_start;
 	while (i < len) {
-		if (base[i] == '>')
+		if (bol && base[i] == '>')
 			n++;
 		const char *nl = (const char *)memchr(base + i, '\n', len - i);
-		if (!nl)
+		if (!nl) {
+			bol = false;
+			i = len;
 			break;
+		}
 		i = (size_t)(nl - base) + 1;
+		bol = true;
 	}
+	*at_line_start = bol;
+	return n;
+}
+
+int64_t fasta_count_records(const char *path)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f)
+		return -1;
+	std::vector<char> buf(8u << 20);
+	int64_t n = 0;
+	bool bol = true;
+	size_t k;
+	while ((k = fread(buf.data(), 1, buf.size(), f)) > 0)
+		n += fasta_count_records_text(buf.data(), k, &bol);
+	fclose(f);
 	return n;
 }
 

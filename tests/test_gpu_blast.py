@@ -67,7 +67,7 @@ def test_blast_synth_device_path_matches_oracle_bytes(pg, workload):
         assert got == "".join(l for l in lines if l.split("\t", 1)[0] in names), (first, count)
 
 
-def test_blast_fasta_path_matches_oracle_bytes(pg, workload, tmp_path):
+def test_blast_fasta_path_matches_oracle_bytes(pg, workload, tmp_path, monkeypatch):
     out = tmp_path / "hits.tsv"
     pg.makeblastdb(str(workload / "db.fa"), str(tmp_path / "db"))
     pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(out))
@@ -76,6 +76,19 @@ def test_blast_fasta_path_matches_oracle_bytes(pg, workload, tmp_path):
     parts = b""
     for rk in range(3):
         p = tmp_path / ("part%d.tsv" % rk)
+        pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(p), rank=rk, world_size=3)
+        parts += p.read_bytes()
+    assert parts == out.read_bytes()
+    # large query files are streamed in pieces that end at record boundaries: force tiny pieces (a few hundred reads,
+    # and one smaller than a record) and shard on top of it
+    for piece in ("50000", "7001", "100"):
+        monkeypatch.setenv("PGX_BLASTN_PIECE", piece)
+        s = tmp_path / ("stream%s.tsv" % piece)
+        pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(s))
+        assert s.read_bytes() == out.read_bytes(), piece
+    parts = b""
+    for rk in range(3):
+        p = tmp_path / ("spart%d.tsv" % rk)
         pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(p), rank=rk, world_size=3)
         parts += p.read_bytes()
     assert parts == out.read_bytes()
