@@ -424,6 +424,7 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	PGX_TRY(db->d_tok_rank.upload(db->h_tok_rank.data(), db->h_tok_rank.size()));
 	{
 		std::vector<uint32_t> pairs(n * 16, 0);
+		db->max_pairs = 0;
 		for (size_t i = 0; i < n; i++) {
 			const uint32_t t0 = off[i], nt = off[i + 1] - t0, np = (nt + 1) / 2;
 			uint32_t *rec = &pairs[i * 16];
@@ -432,6 +433,7 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 				continue;
 			}
 			rec[0] = nt | (np << 16);
+			db->max_pairs = std::max(db->max_pairs, (int)np);
 			for (uint32_t a = 0; a < np; a++) {
 				const uint32_t rk = (uint32_t)(db->h_tok_rank[toks[t0 + 2 * a]] + 1);
 				const uint32_t nm = 2 * a + 1 < nt ? toks[t0 + 2 * a + 1] : 0u;
@@ -572,6 +574,9 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	}
 	pgx_rdp *rd = new pgx_rdp();
 	rd->n = (int64_t)n;
+	rd->max_trip = 0;
+	for (size_t r = 0; r < n; r++)
+		rd->max_trip = std::max(rd->max_trip, (int)std::min<size_t>(per[r].size(), 8));
 	int rc = rd->d_off.alloc(n + 1);
 	if (rc == 0) rc = rd->d_off.upload(off.data(), n + 1);
 	if (rc == 0) rc = rd->d_name.alloc(name.size() ? name.size() : 1);
@@ -625,6 +630,7 @@ int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, c
 	PGX_TRY(d_base.upload(base, 7));
 	pgx_rdp *rd = new pgx_rdp();
 	rd->n = count;
+	rd->max_trip = 6; // the synthetic stream names six ranks per read
 	std::vector<uint32_t> off((size_t)count + 1);
 	for (int64_t i = 0; i <= count; i++)
 		off[(size_t)i] = (uint32_t)(6 * i);

@@ -1035,6 +1035,7 @@ struct ConsView {
 	const uint32_t *subj_pairs; // 16 words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
 	const uint32_t *rdp_code;   // name << 3 | rank + 1 per RDP triplet
 	int dbg;                    // profiling aid (PGX_SORT_STOP): truncate k_sort_consensus after a stage
+	int np_max, nr_max;         // most pairs of any subject record / triplets of any read: the compare grid is np_max x nr_max
 };
 
 // string-order rank of the hit's pident text
@@ -1047,6 +1048,21 @@ __device__ __forceinline__ uint32_t hit_simrank(const ConsView &cv, const pgx_hi
 }
 
 constexpr int kRdpRegs = 8; // RDP triplets of a read kept in registers by the fast agreement count
+
+template <int NP, int NR>
+__device__ __forceinline__ uint32_t pair_grid(const uint32_t (&pr)[15], const uint32_t (&rc)[kRdpRegs], uint32_t np)
+{
+	uint32_t rm = 0;
+#pragma unroll
+	for (int a = 0; a < NP; a++) {
+		if ((uint32_t)a < np) {
+#pragma unroll
+			for (int b = 0; b < NR; b++)
+				rm += pr[a] == rc[b];
+		}
+	}
+	return rm;
+}
 
 // fast (rank,name) agreement: one 64-byte record per subject against the read's RDP codes in registers
 __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t subject, const uint32_t (&rc)[kRdpRegs],
@@ -1065,15 +1081,10 @@ __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t su
 	const uint4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
 	const uint32_t pr[15] = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
 	uint32_t rm = 0;
-#pragma unroll
-	for (int a = 0; a < 15; a++) {
-		if ((uint32_t)a < np) {
-#pragma unroll
-			for (int b = 0; b < kRdpRegs; b++)
-				rm += pr[a] == rc[b];
-		}
-	}
-	return rm;
+	// the compare grid: 7 pairs x 6 triplets for the usual seven-rank lineages (one kernel-uniform branch), 15 x 8 otherwise
+	if (cv.np_max <= 7 && cv.nr_max <= 6)
+		return pair_grid<7, 6>(pr, rc, np);
+	return pair_grid<15, kRdpRegs>(pr, rc, np);
 }
 
 // (rank,name) agreement of one hit with the read's RDP triplets
@@ -1412,6 +1423,8 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 		cv.simrank_undef = db->simrank_undef;
 		cv.simrank_zero = db->simrank_zero;
 	}
+	cv.np_max = db ? db->max_pairs : 15;
+	cv.nr_max = rdp ? rdp->max_trip : kRdpRegs;
 	if (rdp) {
 		cv.rdp_off = rdp->d_off.data();
 		cv.rdp_name = rdp->d_name.data();

@@ -45,6 +45,7 @@ struct pgx_db {
 	// 64-byte record per subject for the consensus kernel: [0] = ntok | npairs << 16 (npairs 0xFFFF: use the
 	// CSR), [1..15] = (name id << 3 | rank index + 1) of each (rank,name) pair
 	pgx::DevBuf<uint32_t> d_subj_pairs;
+	int max_pairs = 15; // most pairs any subject record carries
 	std::vector<int8_t> h_tok_rank;
 	std::vector<int32_t> subj_taxid;
 	// distinct lineage texts (the OTUs megaclust counts): id per subject, text per id; the last id is the empty text
@@ -92,6 +93,7 @@ struct pgx_rdp {
 	pgx::DevBuf<int8_t> d_rank;    // index in (domain..species) or -1
 	pgx::DevBuf<uint32_t> d_code;  // name << 3 | rank + 1 (0xFFFFFFFF: matches nothing)
 	pgx::DevBuf<uint8_t> d_present; // 0: read has no RDP line (never selected)
+	int max_trip = 8;               // most triplets any read of the batch carries (bounds the agreement compare grid)
 };
 
 namespace pgx {
