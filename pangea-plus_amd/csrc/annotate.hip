@@ -13,6 +13,8 @@
 
 #include "bitops.hpp"
 #include "consensus_core.hpp"
+#include <thread>
+
 #include "engine.hpp"
 #include "taxdb.hpp"
 
@@ -121,6 +123,42 @@ static void split_columns(const std::string &line, std::vector<std::string> &f)
 	f.emplace_back(line, s, line.size() - s);
 	while (!f.empty() && f.back().empty())
 		f.pop_back();
+}
+
+// the same line straight from the text: fields of split(/\ |\t\t|\t/) are walked in place (no per-field strings)
+static void emit_collected_fast(const char *line, size_t n, const std::string &lineage, std::string &out)
+{
+	// trailing empty fields are dropped by the split, which only matters for which indices exist: empty fields are
+	// never printed anyway
+	size_t s = 0, i = 0;
+	int field = 0;
+	auto flush = [&](size_t e) {
+		if (field == 0) {
+			out.append(line + s, e - s);
+			out += '\t';
+			out += lineage;
+		} else if (field >= 2 && field <= 12 && e > s) {
+			out += '\t';
+			out.append(line + s, e - s);
+		}
+		field++;
+	};
+	while (i < n) {
+		int sep = 0;
+		if (line[i] == ' ')
+			sep = 1;
+		else if (line[i] == '\t')
+			sep = (i + 1 < n && line[i + 1] == '\t') ? 2 : 1;
+		if (sep) {
+			flush(i);
+			i += sep;
+			s = i;
+		} else {
+			i++;
+		}
+	}
+	flush(n);
+	out += '\n';
 }
 
 // one output line of the driver: id, lineage, then input columns 2..12 that are not empty
@@ -297,26 +335,37 @@ int pgx_taxcollect_file(pgx_taxdb *db, const char *in_path, const char *out_path
 		report.printf("Error: Unable to open classification results file %s.\n", in_path); // taxcollector:31-34
 		return done(fail(PGX_E_IO, "cannot open %s", in_path));
 	}
-	// pass 1 (host): lines up to the first empty one (taxcollector:83-87), their gi texts
-	std::vector<std::string> lines, gis;
+	// pass 1 (host): lines up to the first empty one (taxcollector:83-87) and where their gi texts are; nothing is copied
+	struct LineRef {
+		size_t s, n, g, gn; // line start/length, gi text start/length
+	};
+	std::vector<LineRef> lines;
 	std::vector<int32_t> gi_num;
 	int hang_line = -1;
 	for (size_t s = 0; s < text.size();) {
-		size_t e = text.find('\n', s);
-		if (e == std::string::npos)
-			e = text.size();
-		std::string line(text, s, e - s);
-		s = e + 1;
-		if (line.find_first_not_of('|') == std::string::npos)
+		const char *nl = (const char *)memchr(text.data() + s, '\n', text.size() - s);
+		const size_t e = nl ? (size_t)(nl - text.data()) : text.size();
+		const char *line = text.data() + s;
+		const size_t n = e - s;
+		bool only_bars = true;
+		for (size_t k = 0; k < n && only_bars; k++)
+			only_bars = line[k] == '|';
+		if (only_bars)
 			break;
-		std::string g;
-		if (!gi_text_of(line, g) || g.empty()) {
+		const char *b1 = (const char *)memchr(line, '|', n);
+		size_t g = 0, gn = 0;
+		if (b1) {
+			g = (size_t)(b1 - line) + 1;
+			const char *b2 = (const char *)memchr(line + g, '|', n - g);
+			gn = b2 ? (size_t)(b2 - line) - g : n - g;
+		}
+		if (!b1 || gn == 0) {
 			hang_line = (int)lines.size();
 			break; // `./tax_class -s` without an id: the reference recurses forever
 		}
-		lines.push_back(line);
-		gis.push_back(g);
-		gi_num.push_back(atoi(g.c_str()));
+		lines.push_back({ s, n, s + g, gn });
+		gi_num.push_back(atoi(std::string(line + g, gn).c_str()));
+		s = e + 1;
 	}
 	// pass 2 (device): one walk per line
 	const size_t n = lines.size();
@@ -337,24 +386,67 @@ int pgx_taxcollect_file(pgx_taxdb *db, const char *in_path, const char *out_path
 		if (rc < 0)
 			return done(rc);
 	}
-	// pass 3 (host): text
-	LineageRenderer ren(db);
-	std::string out;
+	// the driver stops at the first line whose walk never ends (or is too long for this build)
+	size_t stop_at = n;
 	int status = 0;
-	for (size_t i = 0; i < n; i++) {
+	for (size_t i = 0; i < n; i++)
 		if (st[i] == 2 || st[i] == 3) {
-			status = st[i] == 2 ? fail(PGX_E_REFHANG, "line %zu (GI %s): the reference driver never terminates on this taxonomy walk", i + 1, gis[i].c_str())
+			stop_at = i;
+			const std::string g(text, lines[i].g, lines[i].gn);
+			status = st[i] == 2 ? fail(PGX_E_REFHANG, "line %zu (GI %s): the reference driver never terminates on this taxonomy walk", i + 1, g.c_str())
 					    : fail(PGX_E_LIMIT, "line %zu: lineage longer than %d elements", i + 1, PGX_LINEAGE_SLOTS);
 			break;
 		}
-		if (st[i] == 1) {
-			report.s += "Searching upper node for TAXID 0\n.\n"; // taxcollector:176 with "0\n"
-			report.printf("\n\nTAXID zero GI = %s.\n\n", gis[i].c_str());
-		} else {
-			report.printf("Searching upper node for TAXID %d.\n", leaf[i]);
-			report.printf("Done for TAXID %d.\n", leaf[i]);
+	// pass 3 (host, all cores): text.  Lines are independent; every worker renders a contiguous block with its own
+	// name cache and remembers the lineage text per gi, the blocks are joined in order.
+	const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, stop_at / 20000 + 1));
+	std::vector<std::string> outs(workers), reps(workers);
+	auto work = [&](unsigned w) {
+		const size_t i0 = stop_at * w / workers, i1 = stop_at * (w + 1) / workers;
+		LineageRenderer ren(db);
+		std::unordered_map<std::string, std::string> memo;
+		std::string &o = outs[w], &r = reps[w];
+		o.reserve((i1 - i0) * 160);
+		r.reserve((i1 - i0) * 64);
+		char buf[96];
+		for (size_t i = i0; i < i1; i++) {
+			const std::string g(text, lines[i].g, lines[i].gn);
+			if (st[i] == 1) {
+				r += "Searching upper node for TAXID 0\n.\n"; // taxcollector:176 with "0\n"
+				r += "\n\nTAXID zero GI = " + g + ".\n\n";
+			} else {
+				const int k = snprintf(buf, sizeof buf, "Searching upper node for TAXID %d.\nDone for TAXID %d.\n", leaf[i], leaf[i]);
+				r.append(buf, (size_t)k);
+			}
+			auto it = memo.find(g);
+			if (it == memo.end())
+				it = memo.emplace(g, ren.render(&lin[i * PGX_LINEAGE_SLOTS], cnt[i], st[i], g)).first;
+			emit_collected_fast(text.data() + lines[i].s, lines[i].n, it->second, o);
 		}
-		emit_collected(lines[i], ren.render(&lin[i * PGX_LINEAGE_SLOTS], cnt[i], st[i], gis[i]), out);
+	};
+	if (workers == 1) {
+		work(0);
+	} else {
+		std::vector<std::thread> th;
+		for (unsigned w = 0; w < workers; w++)
+			th.emplace_back(work, w);
+		for (auto &t : th)
+			t.join();
+	}
+	std::string out;
+	size_t total_out = 0, total_rep = 0;
+	for (unsigned w = 0; w < workers; w++) {
+		total_out += outs[w].size();
+		total_rep += reps[w].size();
+	}
+	out.reserve(total_out);
+	report.s.reserve(report.s.size() + total_rep);
+	for (unsigned w = 0; w < workers; w++) {
+		out += outs[w];
+		report.s += reps[w];
+		std::string().swap(outs[w]);
+		std::string().swap(reps[w]);
 	}
 	if (status == 0 && hang_line >= 0)
 		status = fail(PGX_E_REFHANG, "line %d has no gi|N| subject id: the reference driver never terminates on it", hang_line + 1);
@@ -805,44 +897,75 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 	std::unordered_map<std::string, uint32_t> tmap;
 	std::vector<std::string> ttext;
 	intern_into(tmap, ttext, "");
-	std::vector<std::string> bline, bid, bsim;
+	// Nothing is copied per line: lines and their id are spans of the file text; the lineage column is tokenised once
+	// per DISTINCT lineage text (a hit table names a few hundred thousand lineages millions of times) and the
+	// similarity column is ranked once per distinct text.
+	struct Span {
+		size_t s, n;
+	};
+	std::vector<Span> bline, bid;
 	std::vector<uint32_t> tok_off(1, 0), tok;
 	std::vector<std::string> tk;
+	std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> lin_memo; // lineage text -> (first token, count) in lin_tok
+	std::vector<uint32_t> lin_tok;
+	std::unordered_map<std::string, uint32_t> sim_id; // similarity text -> id
+	std::vector<std::string> sim_text;
+	std::vector<uint32_t> line_simid;
+	std::string key;
 	for (size_t s = 0; s < bt.size();) {
-		size_t e = bt.find('\n', s);
-		if (e == std::string::npos)
-			e = bt.size();
-		bline.emplace_back(bt, s, e - s);
-		s = e + 1;
-		const std::string &ln = bline.back();
-		// split(/\t\t|\t/): trailing empty fields dropped
-		std::vector<std::string> f;
+		const char *nl = (const char *)memchr(bt.data() + s, '\n', bt.size() - s);
+		const size_t e = nl ? (size_t)(nl - bt.data()) : bt.size();
+		const char *ln = bt.data() + s;
+		const size_t n = e - s;
+		bline.push_back({ s, n });
+		// split(/\t\t|\t/): fields 0, 1, 2 in place (a trailing empty field does not exist)
+		Span f[3] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+		int nf = 0;
 		size_t a = 0, i = 0;
-		while (i < ln.size()) {
+		while (i < n && nf < 3) {
 			if (ln[i] == '\t') {
-				f.emplace_back(ln, a, i - a);
-				i += (i + 1 < ln.size() && ln[i + 1] == '\t') ? 2 : 1;
+				f[nf++] = { a, i - a };
+				i += (i + 1 < n && ln[i + 1] == '\t') ? 2 : 1;
 				a = i;
 			} else {
 				i++;
 			}
 		}
-		if (!ln.empty())
-			f.emplace_back(ln, a, ln.size() - a);
-		while (!f.empty() && f.back().empty())
-			f.pop_back();
-		bid.push_back(f.size() > 0 ? f[0] : std::string());
-		bsim.push_back(f.size() > 2 ? f[2] : std::string());
-		lineage_tokens(f.size() > 1 ? f[1] : std::string(), tk);
-		for (auto &t : tk)
-			tok.push_back(intern_into(tmap, ttext, t));
+		if (nf < 3 && n > 0 && a < n)
+			f[nf++] = { a, n - a };
+		bid.push_back({ s + f[0].s, f[0].n });
+		key.assign(ln + f[2].s, f[2].n);
+		auto si = sim_id.find(key);
+		if (si == sim_id.end()) {
+			si = sim_id.emplace(key, (uint32_t)sim_text.size()).first;
+			sim_text.push_back(key);
+		}
+		line_simid.push_back(si->second);
+		key.assign(ln + f[1].s, f[1].n);
+		auto li = lin_memo.find(key);
+		if (li == lin_memo.end()) {
+			lineage_tokens(key, tk);
+			const uint32_t t0 = (uint32_t)lin_tok.size();
+			for (auto &t : tk)
+				lin_tok.push_back(intern_into(tmap, ttext, t));
+			li = lin_memo.emplace(key, std::make_pair(t0, (uint32_t)tk.size())).first;
+		}
+		for (uint32_t k = 0; k < li->second.second; k++)
+			tok.push_back(lin_tok[li->second.first + k]);
 		tok_off.push_back((uint32_t)tok.size());
+		s = e + 1;
 	}
 	std::map<std::string, uint32_t> simrank;
-	build_sim_ranks(bsim, simrank);
+	build_sim_ranks(sim_text, simrank);
+	std::vector<uint32_t> simid_rank(sim_text.size());
+	for (size_t i = 0; i < sim_text.size(); i++)
+		simid_rank[i] = simrank[sim_text[i]];
 	std::vector<uint32_t> line_sim(bline.size());
 	for (size_t i = 0; i < bline.size(); i++)
-		line_sim[i] = simrank[bsim[i]];
+		line_sim[i] = simid_rank[line_simid[i]];
+	auto id_equals = [&](size_t line, const std::string &x) {
+		return bid[line].n == x.size() && memcmp(bt.data() + bid[line].s, x.data(), x.size()) == 0;
+	};
 
 	// ---- RDP lines (Consensus:126-132) and the cursor walk over both files (Consensus:96-240)
 	std::vector<uint32_t> rdp_off(1, 0), rdp_name;
@@ -888,8 +1011,7 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 		uint32_t first = (uint32_t)cur, count = 0;
 		for (;;) {
 			const bool have = cur < bline.size();
-			const std::string &id = have ? bid[cur] : ttext[0];
-			if (id == rid) {
+			if (have ? id_equals(cur, rid) : rid.empty()) {
 				if (!have) {
 					status = fail(PGX_E_REFHANG, "RDP line %u has an empty id after the BLAST table ends: the reference never terminates", rdp_index + 1);
 					break;
@@ -902,6 +1024,7 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 				continue;
 			}
 			if (found == 0) {
+				const std::string id = have ? std::string(bt, bid[cur].s, bid[cur].n) : std::string();
 				log.printf("not found: %s\t %s\n", id.c_str(), rid.c_str()); // Consensus:217
 				if (!have) {
 					status = fail(PGX_E_REFHANG, "RDP read %s has no BLAST lines at or after the cursor: the reference never terminates (SURVEY 3.5)", rid.c_str());
@@ -967,7 +1090,7 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 	std::string out;
 	for (size_t g = 0; g < ng; g++) {
 		if (recs[g].hit >= 0)
-			out += bline[(size_t)recs[g].hit];
+			out.append(bt, bline[(size_t)recs[g].hit].s, bline[(size_t)recs[g].hit].n);
 		out += "\n";
 		char tmp[64];
 		snprintf(tmp, sizeof tmp, "#Matches found: %d\n", recs[g].matches);
