@@ -304,7 +304,7 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	if (!reads->synthetic) {
 		name_off.assign((size_t)reads->n + 1, 0);
 		for (int64_t r = 0; r < reads->n; r++) {
-			name_blob.append(reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+			name_blob.append(*reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
 			name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 		}
 	}
@@ -531,7 +531,7 @@ bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx
 		if (!reads->synthetic) {
 			name_off.assign((size_t)n + 1, 0);
 			for (int64_t r = 0; r < n; r++) {
-				name_blob.append(reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+				name_blob.append(*reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
 				name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 			}
 		}
@@ -683,17 +683,30 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 		const int64_t here = fasta_count_records_text(piece.data(), piece.size(), &bol);
 		const int64_t a = std::max(lo, seen), b = std::min(hi, seen + here);
 		if (a < b) {
-			pgx_reads *rd = nullptr;
-			pgx_hits *h = nullptr;
-			rc = reads_from_fasta_text(std::move(piece), a - seen, b - a, false, nullptr, &rd);
-			if (rc == 0)
-				rc = pgx_blast_search(db, rd, &h);
-			if (rc == 0)
-				rc = format_hits_stream(h, db, rd, [&](const char *p, size_t n) {
-					return fwrite(p, 1, n, fo) == n ? 0 : fail(PGX_E_IO, "short write to %s", o->out_path);
-				});
-			pgx_hits_close(h);
-			pgx_reads_close(rd);
+			// a batch whose hit table does not fit (2^32 slots, or HBM) is halved until it does: reads that hit
+			// tens of thousands of subjects each need small batches, ordinary reads take the whole piece
+			const auto text = std::make_shared<const std::string>(std::move(piece));
+			std::function<int(int64_t, int64_t)> run = [&](int64_t first, int64_t count) -> int {
+				pgx_reads *rd = nullptr;
+				pgx_hits *h = nullptr;
+				int q = reads_from_fasta_text(text, first, count, false, nullptr, &rd);
+				if (q == 0)
+					q = pgx_blast_search(db, rd, &h);
+				const bool searched = q == 0; // nothing of this batch has been written yet if the search failed
+				if (q == 0)
+					q = format_hits_stream(h, db, rd, [&](const char *p, size_t n) {
+						return fwrite(p, 1, n, fo) == n ? 0 : fail(PGX_E_IO, "short write to %s", o->out_path);
+					});
+				pgx_hits_close(h);
+				pgx_reads_close(rd);
+				if (!searched && (q == PGX_E_LIMIT || q == PGX_E_NOMEM) && count > 1) {
+					q = run(first, count / 2);
+					if (q == 0)
+						q = run(first + count / 2, count - count / 2);
+				}
+				return q;
+			};
+			rc = run(a - seen, b - a);
 		}
 		seen += here;
 	}

@@ -1547,7 +1547,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	g_times.postings = (int64_t)h_cnt[2];
 	g_times.candidates = (int64_t)h_cnt[3];
 	g_times.survivors = (int64_t)h_cnt[6];
-	if (H >= (1ull << 32))
+	// (PGX_HIT_LIMIT lowers the limit: tests use it to exercise the callers' batch halving)
+	const unsigned long long hit_limit = getenv("PGX_HIT_LIMIT") ? strtoull(getenv("PGX_HIT_LIMIT"), nullptr, 10) : (1ull << 32);
+	if (H >= hit_limit)
 		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
 			    (unsigned long long)H);
 

@@ -942,13 +942,14 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 		return fail(PGX_E_IO, "cannot open query file %s", path);
 	if (trace)
 		fprintf(stderr, "[pgx trace] reads_from_fasta: file %.1f ms\n", ms(t_begin, now()));
-	return reads_from_fasta_text(std::move(text), first, count, fold_to_g, amb_count, out);
+	return reads_from_fasta_text(std::make_shared<const std::string>(std::move(text)), first, count, fold_to_g, amb_count, out);
 }
 
 // the same for FASTA text already in memory (pgx_blastn_run streams large query files through this in pieces)
-int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
-			  pgx_reads **out)
+int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t first, int64_t count, bool fold_to_g,
+			  std::vector<uint32_t> *amb_count, pgx_reads **out)
 {
+	const std::string &text = *text_ptr;
 	PGX_TRY(require_device());
 	const bool trace = getenv("PGX_TRACE") != nullptr;
 	auto now = [] { return std::chrono::steady_clock::now(); };
@@ -988,8 +989,7 @@ int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool
 	uint64_t nw = 0;
 	rd->name_off.resize((size_t)count);
 	rd->name_len.resize((size_t)count);
-	if (!on_device)
-		rd->h_text.clear();
+	std::string own_names; // host splitter: names are copied out of the header strings
 	for (int64_t i = 0; i < count; i++) {
 		uint64_t L = rec_off[(size_t)(first + i) + 1] - rec_off[(size_t)(first + i)];
 		rd->h_len[(size_t)i] = (uint32_t)L;
@@ -1002,9 +1002,9 @@ int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool
 			rd->name_len[(size_t)i] = df.name_len[(size_t)(first + i)];
 		} else {
 			const std::string nm = first_word(fl.headers[(size_t)(first + i)]);
-			rd->name_off[(size_t)i] = rd->h_text.size();
+			rd->name_off[(size_t)i] = own_names.size();
 			rd->name_len[(size_t)i] = (uint32_t)nm.size();
-			rd->h_text += nm;
+			own_names += nm;
 		}
 	}
 	rd->h_woff[(size_t)count] = (uint32_t)nw;
@@ -1019,8 +1019,9 @@ int reads_from_fasta_text(std::string &&text, int64_t first, int64_t count, bool
 	const unsigned char *d_letters_ptr = nullptr;
 	if (on_device) {
 		d_letters_ptr = df.d_letters.data() + l0;
-		rd->h_text = std::move(text); // names are read from the text on demand
+		rd->h_text = text_ptr; // names are read from the text on demand
 	} else {
+		rd->h_text = std::make_shared<const std::string>(std::move(own_names));
 		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1);
 		if (rc == 0) rc = d_letters_host.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
 		d_letters_ptr = d_letters_host.data();
@@ -1141,7 +1142,7 @@ std::string pgx_reads::name_of(int64_t i) const
 {
 	if (synthetic)
 		return "r" + std::to_string(first + i);
-	return h_text.substr(name_off[(size_t)i], name_len[(size_t)i]);
+	return h_text->substr(name_off[(size_t)i], name_len[(size_t)i]);
 }
 
 using namespace pgx;

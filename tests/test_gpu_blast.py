@@ -86,6 +86,12 @@ def test_blast_fasta_path_matches_oracle_bytes(pg, workload, tmp_path, monkeypat
         s = tmp_path / ("stream%s.tsv" % piece)
         pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(s))
         assert s.read_bytes() == out.read_bytes(), piece
+    # a batch whose hit table would not fit is halved until it does (here: a pretend limit of 5 000 hits)
+    monkeypatch.setenv("PGX_HIT_LIMIT", "5000")
+    s = tmp_path / "halved.tsv"
+    pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(s))
+    assert s.read_bytes() == out.read_bytes()
+    monkeypatch.delenv("PGX_HIT_LIMIT")
     parts = b""
     for rk in range(3):
         p = tmp_path / ("spart%d.tsv" % rk)
