@@ -1148,12 +1148,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 {
 	constexpr int RPW = 64 / G; // reads per wavefront
 	__shared__ SortWave s_sw[kWavesPerBlock];
-	SortWave *sw = &s_sw[threadIdx.x >> 6];
+	const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: scalar registers
+	SortWave *sw = &s_sw[wave_id];
 	const int lane = threadIdx.x & 63;
 	const int g = lane / G, li = lane % G, slot0 = g * G;
 	const uint32_t total = list ? *n_list_ptr : n_reads;
 	uint32_t chunk_base = 0, chunk_used = 64; // this wave's chunk of next_list (G == 32)
-	for (uint32_t base = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW; base < total;
+	for (uint32_t base = (blockIdx.x * kWavesPerBlock + (uint32_t)wave_id) * RPW; base < total;
 	     base += gridDim.x * kWavesPerBlock * RPW) {
 		const uint32_t idx = base + (uint32_t)g;
 		bool valid = idx < total;
