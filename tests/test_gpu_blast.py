@@ -325,3 +325,30 @@ def test_random_mixtures_match_oracle(pg, oracle_bin, tmp_path, seed):
     assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)], timeout=600)[0] == 0
     assert len(want.read_bytes()) > 50000
     assert _blast_text(pg, db, rd, tmp_path, "fz") == want.read_bytes()
+
+
+def test_command_lines_with_the_reference_flags(workload, tmp_path):
+    """`makeblastdb -in F -out P -dbtype nucl` (README.md:62) and `blastn -query F -db P -outfmt 6 -out O`
+    (README.md:96) as executables, incl. the rank/world_size extension that replaces mpiblastn's partition."""
+    import subprocess
+    from conftest import ROOT
+    bin_dir = os.path.join(ROOT, "pangea-plus_amd", "bin")
+    p = subprocess.run([os.path.join(bin_dir, "makeblastdb"), "-in", str(workload / "db.fa"), "-out", str(tmp_path / "nt"), "-dbtype", "nucl"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    p = subprocess.run([os.path.join(bin_dir, "blastn"), "-query", str(workload / "reads.fa"), "-db", str(tmp_path / "nt"), "-outfmt", "6",
+                        "-out", str(tmp_path / "hits.tsv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert (tmp_path / "hits.tsv").read_bytes() == open(workload / "oracle.tsv", "rb").read()
+    parts = b""
+    for rk in range(2):
+        o = tmp_path / ("r%d.tsv" % rk)
+        p = subprocess.run([os.path.join(bin_dir, "blastn"), "-query", str(workload / "reads.fa"), "-db", str(tmp_path / "nt"), "-outfmt", "6",
+                            "-out", str(o), "-rank", str(rk), "-world_size", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr
+        parts += o.read_bytes()
+    assert parts == open(workload / "oracle.tsv", "rb").read()
+    # a missing query file is an error with a message, not a crash
+    p = subprocess.run([os.path.join(bin_dir, "blastn"), "-query", str(tmp_path / "nope.fa"), "-db", str(tmp_path / "nt"), "-outfmt", "6",
+                        "-out", str(tmp_path / "x.tsv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and p.stderr
