@@ -79,106 +79,115 @@ __device__ __forceinline__ uint64_t compress_even(uint64_t x)
 }
 
 // Mismatch flags of one diagonal, two forms with the same interface:
-//   DenseMask  reads of <= 192 bases: the whole diagonal as 3 x 64 one-bit flags in registers, built
+//   DenseMask  reads of <= 64 NW bases (NW = 3 or 5): the whole diagonal as NW x 64 one-bit flags in registers, built
 //              once (5 read words + 5 database windows for a 150-bp read); every scan is bit logic
 //   LazyMask   any length: 32-base words rebuilt on demand (loads served by L1/L2)
-template <bool AMB> struct DenseMask {
+template <bool AMB, int NW> struct DenseMask {
 	static constexpr bool kHasWindows = true;
-	uint64_t m0, m1, m2;
+	static constexpr int kBits = 64 * NW; // bases the flags cover
+	uint64_t m[NW];
 	int lo, hi;
-	// The database and read arrays carry 8 spare words on either side, so the 6 read words and 7 database
-	// words of the diagonal are fetched without per-word range checks (all loads independent); the subject
-	// and read bounds are applied afterwards on the dense flags.
+	// register arrays are only ever indexed by unrolled loop counters; a run-time word index goes through pick()
+	__device__ __forceinline__ static uint64_t pick(const uint64_t (&a)[NW], int wi)
+	{
+		uint64_t v = 0;
+#pragma unroll
+		for (int k = 0; k < NW; k++)
+			v = wi == k ? a[k] : v;
+		return v;
+	}
+	__device__ __forceinline__ static uint64_t below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); }
+	// The database and read arrays carry 24 spare words on either side, so the 2 NW read words and 2 NW + 1
+	// database words of the diagonal are fetched without per-word range checks (all loads independent); the
+	// subject and read bounds are applied afterwards on the dense flags.
 	__device__ __forceinline__ void build(const Diag &D)
 	{
 		lo = D.lo;
 		hi = D.hi;
 		const int64_t wi = D.dstart >> 5;
 		const int sh = (int)(D.dstart & 31) * 2;
-		uint64_t dbv[7], rwv[6];
+		uint64_t dbv[2 * NW + 1], rwv[2 * NW];
 #pragma unroll
-		for (int w = 0; w < 7; w++)
+		for (int w = 0; w < 2 * NW + 1; w++)
 			dbv[w] = D.dbw[wi + w];
 #pragma unroll
-		for (int w = 0; w < 6; w++)
+		for (int w = 0; w < 2 * NW; w++)
 			rwv[w] = D.rw[w];
-		uint64_t d[6];
+		uint64_t d[2 * NW];
 #pragma unroll
-		for (int w = 0; w < 6; w++) {
+		for (int w = 0; w < 2 * NW; w++) {
 			const uint64_t win = sh ? (dbv[w] >> sh) | (dbv[w + 1] << (64 - sh)) : dbv[w];
 			const uint64_t x = rwv[w] ^ win;
-			uint64_t m = (x | (x >> 1)) & kEven;
+			uint64_t mm = (x | (x >> 1)) & kEven;
 			if (AMB) {
 				if (D.ra)
-					m |= D.ra[w];
+					mm |= D.ra[w];
 				if (D.dba)
-					m |= window64(D.dba, D.dstart + 32 * w);
+					mm |= window64(D.dba, D.dstart + 32 * w);
 			}
-			d[w] = compress_even(m);
+			d[w] = compress_even(mm);
 		}
-		m0 = d[0] | (d[1] << 32);
-		m1 = d[2] | (d[3] << 32);
-		m2 = d[4] | (d[5] << 32);
 		// flag everything outside [lo, hi)
-		auto below = [](int n) -> uint64_t { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); };
-		m0 |= below(lo) | ~below(hi);
-		m1 |= below(lo - 64) | ~below(hi - 64);
-		m2 |= below(lo - 128) | ~below(hi - 128);
+#pragma unroll
+		for (int k = 0; k < NW; k++)
+			m[k] = (d[2 * k] | (d[2 * k + 1] << 32)) | below(lo - 64 * k) | ~below(hi - 64 * k);
 	}
 	// w[i] set iff positions i .. i+27 all match (a 28-window of matches starts at i): log-step doubling
 	// 2,4,8,16 then 16+8 and 24+4; every exact run >= 28 shows up as a run of set bits from its start
 	struct Win {
-		uint64_t w0, w1, w2;
+		uint64_t w[NW];
 	};
+	template <int K> __device__ __forceinline__ static void and_shr(const uint64_t (&a)[NW], const uint64_t (&src)[NW], uint64_t (&o)[NW])
+	{
+		// o = a & (src >> K) across the NW words
+#pragma unroll
+		for (int k = 0; k < NW; k++) {
+			const uint64_t up = k + 1 < NW ? src[k + 1] : 0ull;
+			o[k] = a[k] & ((src[k] >> K) | (up << (64 - K)));
+		}
+	}
 	__device__ __forceinline__ Win seed_windows() const
 	{
-		uint64_t r0 = ~m0, r1 = ~m1, r2 = ~m2;
-#define PGX_SHR(k, a0, a1, a2, o0, o1, o2)                                                                             \
-		const uint64_t o0 = ((a0) >> (k)) | ((a1) << (64 - (k))), o1 = ((a1) >> (k)) | ((a2) << (64 - (k))),   \
-			       o2 = (a2) >> (k);
-		PGX_SHR(1, r0, r1, r2, s0, s1, s2)
-		const uint64_t a20 = r0 & s0, a21 = r1 & s1, a22 = r2 & s2;
-		PGX_SHR(2, a20, a21, a22, t0, t1, t2)
-		const uint64_t a40 = a20 & t0, a41 = a21 & t1, a42 = a22 & t2;
-		PGX_SHR(4, a40, a41, a42, u0, u1, u2)
-		const uint64_t a80 = a40 & u0, a81 = a41 & u1, a82 = a42 & u2;
-		PGX_SHR(8, a80, a81, a82, v0, v1, v2)
-		const uint64_t b0 = a80 & v0, b1 = a81 & v1, b2 = a82 & v2; // 16
-		PGX_SHR(16, a80, a81, a82, x0, x1, x2)
-		const uint64_t c0 = b0 & x0, c1 = b1 & x1, c2 = b2 & x2; // 24
-		PGX_SHR(24, a40, a41, a42, y0, y1, y2)
-#undef PGX_SHR
+		uint64_t r[NW], a2[NW], a4[NW], a8[NW], b16[NW], c24[NW];
+#pragma unroll
+		for (int k = 0; k < NW; k++)
+			r[k] = ~m[k];
+		and_shr<1>(r, r, a2);
+		and_shr<2>(a2, a2, a4);
+		and_shr<4>(a4, a4, a8);
+		and_shr<8>(a8, a8, b16);
+		and_shr<16>(b16, a8, c24);
 		Win w;
-		w.w0 = c0 & y0; // 28
-		w.w1 = c1 & y1;
-		w.w2 = c2 & y2;
+		and_shr<24>(c24, a4, w.w);
 		return w;
 	}
 	// is any window bit set below position n?
 	__device__ __forceinline__ static bool win_any_below(const Win &w, int n)
 	{
-		auto below = [](int k) -> uint64_t { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1)); };
-		return ((w.w0 & below(n)) | (w.w1 & below(n - 64)) | (w.w2 & below(n - 128))) != 0;
+		uint64_t any = 0;
+#pragma unroll
+		for (int k = 0; k < NW; k++)
+			any |= w.w[k] & below(n - 64 * k);
+		return any != 0;
 	}
-	// lowest window bit at position >= n, or 192
-	__device__ __forceinline__ static int win_first_ge(const Win &w, int n)
+	// lowest set bit of a[] at position >= n, or kBits
+	__device__ __forceinline__ static int first_set_ge(const uint64_t (&a)[NW], int n)
 	{
-		const uint64_t a0 = n < 64 ? w.w0 & (n <= 0 ? ~0ull : (~0ull << n)) : 0ull;
-		const uint64_t a1 = n < 64 ? w.w1 : (n < 128 ? w.w1 & (~0ull << (n - 64)) : 0ull);
-		const uint64_t a2 = n < 128 ? w.w2 : (n < 192 ? w.w2 & (~0ull << (n - 128)) : 0ull);
-		return a0 ? __ffsll((unsigned long long)a0) - 1
-			  : (a1 ? 63 + __ffsll((unsigned long long)a1) : (a2 ? 127 + __ffsll((unsigned long long)a2) : 192));
+		int r = kBits;
+#pragma unroll
+		for (int k = NW - 1; k >= 0; k--) {
+			const uint64_t v = a[k] & ~below(n - 64 * k);
+			r = v ? 64 * k + __ffsll((unsigned long long)v) - 1 : r;
+		}
+		return r;
 	}
+	__device__ __forceinline__ static int win_first_ge(const Win &w, int n) { return first_set_ge(w.w, n); }
 	// smallest flagged position >= pos, or hi
 	__device__ __forceinline__ int first_ge(int pos) const
 	{
 		if (pos >= hi)
 			return hi;
-		uint64_t a0 = pos < 64 ? m0 & (~0ull << pos) : 0ull;
-		uint64_t a1 = pos < 64 ? m1 : (pos < 128 ? m1 & (~0ull << (pos - 64)) : 0ull);
-		uint64_t a2 = pos < 128 ? m2 : m2 & (~0ull << (pos - 128));
-		int r = a0 ? __ffsll((unsigned long long)a0) - 1
-			   : (a1 ? 63 + __ffsll((unsigned long long)a1) : (a2 ? 127 + __ffsll((unsigned long long)a2) : 192));
+		const int r = first_set_ge(m, pos);
 		return r < hi ? r : hi;
 	}
 	// largest flagged position < pos, or lo-1
@@ -186,10 +195,12 @@ template <bool AMB> struct DenseMask {
 	{
 		if (pos <= lo)
 			return lo - 1;
-		uint64_t b0 = pos >= 64 ? m0 : m0 & ((1ull << pos) - 1);
-		uint64_t b1 = pos >= 128 ? m1 : (pos > 64 ? m1 & ((1ull << (pos - 64)) - 1) : 0ull);
-		uint64_t b2 = pos >= 192 ? m2 : (pos > 128 ? m2 & ((1ull << (pos - 128)) - 1) : 0ull);
-		int r = b2 ? 191 - __clzll((long long)b2) : (b1 ? 127 - __clzll((long long)b1) : (b0 ? 63 - __clzll((long long)b0) : -1));
+		int r = -1;
+#pragma unroll
+		for (int k = 0; k < NW; k++) {
+			const uint64_t v = m[k] & below(pos - 64 * k);
+			r = v ? 64 * k + 63 - __clzll((long long)v) : r;
+		}
 		return r >= lo ? r : lo - 1;
 	}
 	// Cursors over the flags for the X-drop walks: the current 64-flag word is consumed bit by bit
@@ -198,23 +209,22 @@ template <bool AMB> struct DenseMask {
 		uint64_t w;
 		int wi;
 	};
-	// flagged positions > k, ascending (k in [-1, 191])
+	// flagged positions > k, ascending (k in [-1, kBits - 1])
 	__device__ __forceinline__ Fwd fwd_from(int k) const
 	{
 		const int pos = k + 1;
 		Fwd c;
 		c.wi = pos >> 6;
-		const uint64_t word = c.wi == 0 ? m0 : (c.wi == 1 ? m1 : (c.wi == 2 ? m2 : 0ull));
-		c.w = word & (~0ull << (pos & 63));
+		c.w = pick(m, c.wi) & (~0ull << (pos & 63));
 		return c;
 	}
 	__device__ __forceinline__ int fwd_next(Fwd &c) const
 	{
 		while (!c.w) {
 			c.wi++;
-			if (c.wi >= 3)
+			if (c.wi >= NW)
 				return hi;
-			c.w = c.wi == 1 ? m1 : m2;
+			c.w = pick(m, c.wi);
 		}
 		const int r = c.wi * 64 + __ffsll((unsigned long long)c.w) - 1;
 		c.w &= c.w - 1;
@@ -224,7 +234,7 @@ template <bool AMB> struct DenseMask {
 		uint64_t w;
 		int wi;
 	};
-	// flagged positions < k, descending (k in [0, 192])
+	// flagged positions < k, descending (k in [0, kBits])
 	__device__ __forceinline__ Bwd bwd_from(int k) const
 	{
 		Bwd c;
@@ -233,10 +243,9 @@ template <bool AMB> struct DenseMask {
 			c.wi = 0;
 			return c;
 		}
-		const int q = k - 1, b = q & 63;
+		const int q = k - 1, bb = q & 63;
 		c.wi = q >> 6;
-		const uint64_t word = c.wi == 0 ? m0 : (c.wi == 1 ? m1 : m2);
-		c.w = word & (b == 63 ? ~0ull : ((2ull << b) - 1));
+		c.w = pick(m, c.wi) & (bb == 63 ? ~0ull : ((2ull << bb) - 1));
 		return c;
 	}
 	__device__ __forceinline__ int bwd_next(Bwd &c) const
@@ -245,11 +254,11 @@ template <bool AMB> struct DenseMask {
 			if (c.wi == 0)
 				return lo - 1;
 			c.wi--;
-			c.w = c.wi == 0 ? m0 : m1;
+			c.w = pick(m, c.wi);
 		}
-		const int b = 63 - __clzll((long long)c.w);
-		c.w ^= 1ull << b;
-		const int r = c.wi * 64 + b;
+		const int bb = 63 - __clzll((long long)c.w);
+		c.w ^= 1ull << bb;
+		const int r = c.wi * 64 + bb;
 		return r >= lo ? r : lo - 1;
 	}
 };
@@ -561,11 +570,12 @@ __device__ __forceinline__ void lds_fence()
 // lanes 0-31 probe the first, lanes 32-63 the second, their postings are dealt together and their candidates
 // drained together (160 candidates fill 64-lane drains far better than 80), each read staging its hits in
 // its own half of the stage.  Longer reads keep the wavefront to themselves.
-template <bool AMB, bool DENSE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
+template <bool AMB, int NW>
+__global__ __launch_bounds__(64 * kWavesPerBlock, NW <= 3 ? 4 : (NW <= 5 ? 3 : 2)) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
 								      uint32_t *__restrict__ read_cnt,
 								      uint32_t *__restrict__ read_start)
 {
+	constexpr bool DENSE = NW > 0; // NW x 64 one-bit flags per diagonal in registers (0: lazy 32-base words, any length)
 	constexpr int RPW = DENSE ? 2 : 1;
 	constexpr int LPR = 64 / RPW;                     // probe lanes per read
 	constexpr unsigned int SLOT_CAP = kStage;         // staged hits per read (16-byte records when two reads share)
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void k_seed_extend(DbView d
 				}
 				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh); };
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, DenseMask<AMB, (NW > 0 ? NW : 3)>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 				else
 					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 			}
@@ -1506,7 +1516,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	DevBuf<uint32_t> &read_start = g_ws.read_start;
 	PGX_TRY(read_start.ensure(n));
 	unsigned long long h_cnt[8];
-	const bool dense = rd->max_len <= 192;
+	// flags of a whole diagonal in registers: 3 words for reads of <= 192 bases, 5 up to 320, 8 up to 512; longer: lazy words
+	const int mask_words = rd->max_len <= 192 ? 3 : (rd->max_len <= 320 ? 5 : (rd->max_len <= 512 ? 8 : 0));
+	const bool dense = mask_words > 0;
 	for (;;) {
 		PGX_TRY(scratch.ensure(cap));
 		PGX_TRY(ovf.ensure(ovf_cap));
@@ -1521,14 +1533,23 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		ov.counters = counters.data();
 		t.start();
 		const dim3 g(dense ? grid_seed : grid), b(64 * kWavesPerBlock);
-		if (amb && dense)
-			hipLaunchKernelGGL((k_seed_extend<true, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+		uint32_t *rc_ptr = out->d_read_cnt.data(), *rs_ptr = read_start.data();
+		if (amb && mask_words == 3)
+			hipLaunchKernelGGL((k_seed_extend<true, 3>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		else if (amb && mask_words == 5)
+			hipLaunchKernelGGL((k_seed_extend<true, 5>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		else if (amb && mask_words == 8)
+			hipLaunchKernelGGL((k_seed_extend<true, 8>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
 		else if (amb)
-			hipLaunchKernelGGL((k_seed_extend<true, false>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
-		else if (dense)
-			hipLaunchKernelGGL((k_seed_extend<false, true>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+			hipLaunchKernelGGL((k_seed_extend<true, 0>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		else if (mask_words == 3)
+			hipLaunchKernelGGL((k_seed_extend<false, 3>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		else if (mask_words == 5)
+			hipLaunchKernelGGL((k_seed_extend<false, 5>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		else if (mask_words == 8)
+			hipLaunchKernelGGL((k_seed_extend<false, 8>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
 		else
-			hipLaunchKernelGGL((k_seed_extend<false, false>), g, b, 0, 0, dv, rv, ov, out->d_read_cnt.data(), read_start.data());
+			hipLaunchKernelGGL((k_seed_extend<false, 0>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
 		trace_point("k_seed_extend");
 		PGX_HIP(hipGetLastError());
 		g_times.seed_extend_ms = t.stop();

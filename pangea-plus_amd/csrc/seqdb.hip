@@ -519,10 +519,10 @@ int db_upload_and_index(pgx_db *db)
 		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 31-bit position limit of this build",
 			    (long long)db->n_bases);
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
-	PGX_TRY(db->d_words.alloc(nw, 8, 8, true));
+	PGX_TRY(db->d_words.alloc(nw, 24, 24, true));
 	PGX_TRY(db->d_words.upload(db->h_words.data(), std::min(nw, db->h_words.size())));
 	if (db->has_amb) {
-		PGX_TRY(db->d_amb.alloc(nw, 8, 8, true));
+		PGX_TRY(db->d_amb.alloc(nw, 24, 24, true));
 		PGX_TRY(db->d_amb.upload(db->h_amb.data(), std::min(nw, db->h_amb.size())));
 	}
 	PGX_TRY(db_upload_offsets(db));
@@ -730,7 +730,7 @@ static int reads_finish(pgx_reads *rd)
 		PGX_TRY(rd->d_woff.alloc((size_t)rd->n + 1));
 		PGX_TRY(rd->d_woff.upload(rd->h_woff.data(), (size_t)rd->n + 1));
 	}
-	PGX_TRY(rd->d_rc.alloc((size_t)rd->n_words + 8, 0, 0, true));
+	PGX_TRY(rd->d_rc.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	if (rd->n == 0)
 		return 0;
 	int grid = (int)std::min<int64_t>(rd->n, 65535 * 16);
@@ -739,7 +739,7 @@ static int reads_finish(pgx_reads *rd)
 			   rd->d_len.data(), (uint64_t)rd->n, rd->d_rc.data(), 0);
 	PGX_HIP(hipGetLastError());
 	if (rd->has_amb) {
-		PGX_TRY(rd->d_rc_amb.alloc((size_t)rd->n_words + 8, 0, 0, true));
+		PGX_TRY(rd->d_rc_amb.alloc((size_t)rd->n_words + 24, 0, 0, true));
 		hipLaunchKernelGGL(k_revcomp, dim3(grid), dim3(block), 0, 0, rd->d_fwd_amb.data(), rd->d_woff.data(),
 				   rd->d_len.data(), (uint64_t)rd->n, rd->d_rc_amb.data(), 1);
 		PGX_HIP(hipGetLastError());
@@ -1035,8 +1035,8 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 	if (rc == 0) rc = d_flag.alloc(1, 0, 0, true);
 	if (rc == 0) rc = rd->d_woff.alloc((size_t)count + 1);
 	if (rc == 0) rc = rd->d_woff.upload(rd->h_woff.data(), (size_t)count + 1);
-	if (rc == 0) rc = rd->d_fwd.alloc((size_t)nw + 8, 0, 0, true);
-	if (rc == 0 && !fold_to_g) rc = rd->d_fwd_amb.alloc((size_t)nw + 8, 0, 0, true);
+	if (rc == 0) rc = rd->d_fwd.alloc((size_t)nw + 24, 0, 0, true);
+	if (rc == 0 && !fold_to_g) rc = rd->d_fwd_amb.alloc((size_t)nw + 24, 0, 0, true);
 	if (rc == 0 && count > 0) {
 		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, 0, d_letters_ptr, d_loff.data(),
 				   rd->d_woff.data(), (uint64_t)count, fold_to_g ? 1 : 0, rd->d_fwd.data(),
@@ -1242,7 +1242,7 @@ int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out)
 	db->synthetic_ids = true;
 	synth_ids(db);
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
-	int rc = db->d_words.alloc(nw, 8, 8, true);
+	int rc = db->d_words.alloc(nw, 24, 24, true);
 	if (rc == 0) {
 		hipLaunchKernelGGL(k_synth_db, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, 0, cfg->seed,
 				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint64_t)cfg->n_genus,
@@ -1278,7 +1278,7 @@ int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count,
 	rd->h_woff.resize((size_t)count + 1);
 	for (int64_t i = 0; i <= count; i++)
 		rd->h_woff[(size_t)i] = (uint32_t)(i * wpr);
-	int rc = rd->d_fwd.alloc((size_t)rd->n_words + 8, 0, 0, true);
+	int rc = rd->d_fwd.alloc((size_t)rd->n_words + 24, 0, 0, true);
 	if (rc == 0 && count > 0) {
 		uint64_t nt = (uint64_t)count * wpr;
 		hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, cfg->seed,
@@ -1377,9 +1377,9 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 	db->n_postings = s->n_postings;
 	db->synthetic_ids = s->synthetic_ids != 0;
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
-	int rc = db->d_words.alloc(nw, 8, 8, true);
+	int rc = db->d_words.alloc(nw, 24, 24, true);
 	if (rc == 0 && db->has_amb)
-		rc = db->d_amb.alloc(nw, 8, 8, true);
+		rc = db->d_amb.alloc(nw, 24, 24, true);
 	if (rc == 0)
 		rc = db->d_seq_off.alloc((size_t)db->n_seq + 1);
 	if (rc == 0)

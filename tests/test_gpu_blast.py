@@ -352,3 +352,24 @@ def test_command_lines_with_the_reference_flags(workload, tmp_path):
     p = subprocess.run([os.path.join(bin_dir, "blastn"), "-query", str(tmp_path / "nope.fa"), "-db", str(tmp_path / "nt"), "-outfmt", "6",
                         "-out", str(tmp_path / "x.tsv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode != 0 and p.stderr
+
+
+@pytest.mark.parametrize("read_len", [193, 250, 320, 321, 450, 512, 513])
+def test_reads_of_200_to_512_bases_keep_their_flags_in_registers(pg, oracle_bin, tmp_path, read_len):
+    """MiSeq / 454-length reads: diagonals of up to 320 (512) bases are held as 5 (8) x 64 flags in registers (two reads per
+    wavefront, one candidate per diagonal); 513 falls to the any-length path.  Clean ACGT, so the unambiguous kernels run."""
+    from pangea_plus_amd import _capi
+    args = ["--n-seq", "1500", "--seq-len", "700", "--n-genus", "40", "--read-len", str(read_len)]
+    rd, out = tmp_path / "reads.fa", tmp_path / "oracle.tsv"
+    db_fa = tmp_path / "db.fa"
+    assert run_cmd([oracle_bin, "synth", "db", "--out", str(db_fa)] + args)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "reads", "--out", str(rd), "--count", "1201"] + args)[0] == 0
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db_fa), "-outfmt", "6", "-out", str(out), "-num_threads", "8"],
+                   timeout=600)[0] == 0
+    cfg = pg.SynthCfg.default(n_seq=1500, seq_len=700, n_genus=40, read_len=read_len)
+    db = pg.Db.from_synth(cfg)
+    reads = pg.Reads.from_synth(cfg, 0, 1201)
+    hits = _capi.blast_search(db, reads)
+    want = out.read_bytes()
+    assert len(want) > 100000
+    assert hits.format(db, reads) == want
