@@ -38,7 +38,8 @@ struct DbView {
 struct ReadsView {
 	const uint64_t *fwd, *rc, *fwd_amb, *rc_amb;
 	const uint32_t *len, *woff;
-	uint32_t n;
+	uint32_t n;           // reads this launch works on
+	const uint32_t *list; // their ids (null: 0 .. n-1): a batch is searched class by class (flag words, ambiguity)
 };
 
 // ------------------------------------------------------------------------------------------ diagonal masks
@@ -97,6 +98,7 @@ template <bool AMB, int NW> struct DenseMask {
 		return v;
 	}
 	__device__ __forceinline__ static uint64_t below(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1)); }
+	__device__ __forceinline__ static uint64_t from(int n) { return n <= 0 ? ~0ull : (n >= 64 ? 0ull : (~0ull << n)); } // bits at positions >= n
 	// The database and read arrays carry 24 spare words on either side, so the 2 NW read words and 2 NW + 1
 	// database words of the diagonal are fetched without per-word range checks (all loads independent); the
 	// subject and read bounds are applied afterwards on the dense flags.
@@ -130,7 +132,7 @@ template <bool AMB, int NW> struct DenseMask {
 		// flag everything outside [lo, hi)
 #pragma unroll
 		for (int k = 0; k < NW; k++)
-			m[k] = (d[2 * k] | (d[2 * k + 1] << 32)) | below(lo - 64 * k) | ~below(hi - 64 * k);
+			m[k] = (d[2 * k] | (d[2 * k + 1] << 32)) | below(lo - 64 * k) | from(hi - 64 * k);
 	}
 	// w[i] set iff positions i .. i+27 all match (a 28-window of matches starts at i): log-step doubling
 	// 2,4,8,16 then 16+8 and 24+4; every exact run >= 28 shows up as a run of set bits from its start
@@ -176,7 +178,7 @@ template <bool AMB, int NW> struct DenseMask {
 		int r = kBits;
 #pragma unroll
 		for (int k = NW - 1; k >= 0; k--) {
-			const uint64_t v = a[k] & ~below(n - 64 * k);
+			const uint64_t v = a[k] & from(n - 64 * k);
 			r = v ? 64 * k + __ffsll((unsigned long long)v) - 1 : r;
 		}
 		return r;
@@ -570,7 +572,8 @@ __device__ __forceinline__ void lds_fence()
 // lanes 0-31 probe the first, lanes 32-63 the second, their postings are dealt together and their candidates
 // drained together (160 candidates fill 64-lane drains far better than 80), each read staging its hits in
 // its own half of the stage.  Longer reads keep the wavefront to themselves.
-template <bool AMB, int NW>
+// LISTED: the launch works on the reads named by rd.list (one search class of a mixed batch) instead of 0 .. n-1
+template <bool AMB, int NW, bool LISTED>
 __global__ __launch_bounds__(64 * kWavesPerBlock, NW <= 3 ? 4 : (NW <= 5 ? 3 : 2)) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
 								      uint32_t *__restrict__ read_cnt,
 								      uint32_t *__restrict__ read_start)
@@ -590,8 +593,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW <= 3 ? 4 : (NW <= 5 ? 3 : 2
 
 	for (uint32_t rbase = (blockIdx.x * kWavesPerBlock + wave) * RPW; rbase < rd.n; rbase += gridDim.x * kWavesPerBlock * RPW) {
 		// wave-uniform description of the (up to) two reads
-		const uint32_t rA = rbase, rB = rbase + 1;
-		const bool hasB = RPW == 2 && rB < rd.n;
+		const bool hasB = RPW == 2 && rbase + 1 < rd.n;
+		const uint32_t rA = LISTED ? rd.list[rbase] : rbase, rB = LISTED ? (hasB ? rd.list[rbase + 1] : 0u) : rbase + 1;
 		const int LA = (int)rd.len[rA], LB = hasB ? (int)rd.len[rB] : 0;
 		const uint32_t wA = rd.woff[rA], wB = hasB ? rd.woff[rB] : 0u;
 		// this lane's own read (for the probe phase)
@@ -1416,6 +1419,7 @@ static ReadsView reads_view(const pgx_reads *rd)
 	v.len = rd->d_len.data();
 	v.woff = rd->d_woff.data();
 	v.n = (uint32_t)rd->n;
+	v.list = nullptr;
 	return v;
 }
 
@@ -1502,9 +1506,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	index_check(db, "search_pipeline");
 	const DbView dv = db_view(db);
 	const ReadsView rv = reads_view(rd);
-	const bool amb = db->has_amb || rd->has_amb;
 	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
-	const int grid_seed = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
 	EventTimer total, t;
 	total.start();
 
@@ -1516,9 +1518,12 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	DevBuf<uint32_t> &read_start = g_ws.read_start;
 	PGX_TRY(read_start.ensure(n));
 	unsigned long long h_cnt[8];
-	// flags of a whole diagonal in registers: 3 words for reads of <= 192 bases, 5 up to 320, 8 up to 512; longer: lazy words
-	const int mask_words = rd->max_len <= 192 ? 3 : (rd->max_len <= 320 ? 5 : (rd->max_len <= 512 ? 8 : 0));
-	const bool dense = mask_words > 0;
+	// reads are searched class by class (engine.hpp: pgx_reads::classes); a database with ambiguity letters makes every
+	// class ambiguity-aware
+	const std::vector<pgx_reads::SearchClass> &classes = rd->classes;
+	bool dense = true; // every read keeps its flags in registers (the ordering kernels then see no read longer than 512)
+	for (auto &c : classes)
+		dense = dense && c.words > 0;
 	for (;;) {
 		PGX_TRY(scratch.ensure(cap));
 		PGX_TRY(ovf.ensure(ovf_cap));
@@ -1532,24 +1537,41 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		ov.ovf_cap = ovf_cap;
 		ov.counters = counters.data();
 		t.start();
-		const dim3 g(dense ? grid_seed : grid), b(64 * kWavesPerBlock);
-		uint32_t *rc_ptr = out->d_read_cnt.data(), *rs_ptr = read_start.data();
-		if (amb && mask_words == 3)
-			hipLaunchKernelGGL((k_seed_extend<true, 3>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (amb && mask_words == 5)
-			hipLaunchKernelGGL((k_seed_extend<true, 5>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (amb && mask_words == 8)
-			hipLaunchKernelGGL((k_seed_extend<true, 8>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (amb)
-			hipLaunchKernelGGL((k_seed_extend<true, 0>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (mask_words == 3)
-			hipLaunchKernelGGL((k_seed_extend<false, 3>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (mask_words == 5)
-			hipLaunchKernelGGL((k_seed_extend<false, 5>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else if (mask_words == 8)
-			hipLaunchKernelGGL((k_seed_extend<false, 8>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
-		else
-			hipLaunchKernelGGL((k_seed_extend<false, 0>), g, b, 0, 0, dv, rv, ov, rc_ptr, rs_ptr);
+		for (const pgx_reads::SearchClass &c0 : classes) {
+			pgx_reads::SearchClass c = c0;
+			c.amb = c.amb || db->has_amb;
+			ReadsView cvw = rv;
+			const uint64_t cn = c.count;
+			cvw.n = (uint32_t)cn;
+			cvw.list = c.listed ? rd->d_class_list.data() + c.off : nullptr;
+			const int per_block = kWavesPerBlock * (c.words > 0 ? 2 : 1);
+			const dim3 g((unsigned)std::min<uint64_t>((cn + per_block - 1) / per_block, 256ull * 8)), b(64 * kWavesPerBlock);
+			uint32_t *rc_ptr = out->d_read_cnt.data(), *rs_ptr = read_start.data();
+#define PGX_SEED_LAUNCH(A, W)                                                                                                      \
+	do {                                                                                                                       \
+		if (c.listed)                                                                                                      \
+			hipLaunchKernelGGL((k_seed_extend<A, W, true>), g, b, 0, 0, dv, cvw, ov, rc_ptr, rs_ptr);                 \
+		else                                                                                                               \
+			hipLaunchKernelGGL((k_seed_extend<A, W, false>), g, b, 0, 0, dv, cvw, ov, rc_ptr, rs_ptr);                \
+	} while (0)
+			if (c.amb && c.words == 3)
+				PGX_SEED_LAUNCH(true, 3);
+			else if (c.amb && c.words == 5)
+				PGX_SEED_LAUNCH(true, 5);
+			else if (c.amb && c.words == 8)
+				PGX_SEED_LAUNCH(true, 8);
+			else if (c.amb)
+				PGX_SEED_LAUNCH(true, 0);
+			else if (c.words == 3)
+				PGX_SEED_LAUNCH(false, 3);
+			else if (c.words == 5)
+				PGX_SEED_LAUNCH(false, 5);
+			else if (c.words == 8)
+				PGX_SEED_LAUNCH(false, 8);
+			else
+				PGX_SEED_LAUNCH(false, 0);
+#undef PGX_SEED_LAUNCH
+		}
 		trace_point("k_seed_extend");
 		PGX_HIP(hipGetLastError());
 		g_times.seed_extend_ms = t.stop();

@@ -71,6 +71,17 @@ struct pgx_reads {
 	std::vector<uint64_t> name_off;
 	std::vector<uint32_t> name_len;
 	std::vector<uint32_t> h_len, h_woff;
+	std::vector<uint8_t> h_read_amb; // per read: holds an ambiguity letter (empty: none does)
+	// search classes (built once when the batch is made): reads are searched class by class -- flag words of a
+	// diagonal (3: <= 192 bases, 5: <= 320, 8: <= 512, 0: longer) x ambiguity letters -- so that a few long or
+	// N-holding reads do not slow down the rest.  One class without a list = the whole batch.
+	struct SearchClass {
+		int amb, words;
+		uint32_t off, count;
+		bool listed;
+	};
+	std::vector<SearchClass> classes;
+	pgx::DevBuf<uint32_t> d_class_list;
 	std::vector<uint64_t> h_fwd; // host copy of the forward strand (file-built batches only)
 	int64_t n_words = 0;
 	int32_t max_len = 0;

@@ -721,8 +721,43 @@ __global__ void k_synth_reads(uint64_t seed, uint64_t n_seq, uint32_t seq_len, u
 	fwd[t] = out;
 }
 
+static int reads_build_classes(pgx_reads *rd)
+{
+	auto words_for = [](uint32_t L) { return L <= 192u ? 3 : (L <= 320u ? 5 : (L <= 512u ? 8 : 0)); };
+	const size_t n = (size_t)rd->n;
+	rd->classes.clear();
+	const bool per_read_amb = rd->has_amb && rd->h_read_amb.size() == n;
+	bool uniform = true;
+	const int w0 = words_for(n ? rd->h_len[0] : (uint32_t)rd->max_len);
+	if (!rd->synthetic) // synthetic batches have one length and no ambiguity letters
+		for (size_t r = 0; r < n && uniform; r++)
+			uniform = words_for(rd->h_len[r]) == w0 && !(per_read_amb && rd->h_read_amb[r] != rd->h_read_amb[0]);
+	if (uniform) {
+		const int a = rd->has_amb && (!per_read_amb || (n && rd->h_read_amb[0]));
+		rd->classes.push_back({ a, w0, 0u, (uint32_t)n, false });
+		return 0;
+	}
+	std::vector<uint32_t> ids[8];
+	for (size_t r = 0; r < n; r++) {
+		const int a = rd->has_amb && (!per_read_amb || rd->h_read_amb[r]);
+		const int w = words_for(rd->h_len[r]);
+		ids[a * 4 + (w == 3 ? 0 : w == 5 ? 1 : w == 8 ? 2 : 3)].push_back((uint32_t)r);
+	}
+	std::vector<uint32_t> all;
+	all.reserve(n);
+	static const int kWords[4] = { 3, 5, 8, 0 };
+	for (int c = 0; c < 8; c++)
+		if (!ids[c].empty()) {
+			rd->classes.push_back({ c / 4, kWords[c % 4], (uint32_t)all.size(), (uint32_t)ids[c].size(), true });
+			all.insert(all.end(), ids[c].begin(), ids[c].end());
+		}
+	PGX_TRY(rd->d_class_list.alloc(all.size()));
+	return rd->d_class_list.upload(all.data(), all.size());
+}
+
 static int reads_finish(pgx_reads *rd)
 {
+	PGX_TRY(reads_build_classes(rd));
 	// d_fwd (and d_fwd_amb) are filled; build offsets/lengths on device and the rc strand
 	PGX_TRY(rd->d_len.alloc((size_t)rd->n));
 	PGX_TRY(rd->d_len.upload(rd->h_len.data(), (size_t)rd->n));
@@ -1049,6 +1084,14 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 	rd->has_amb = flag != 0 && !fold_to_g;
 	if (rc == 0 && !rd->has_amb)
 		rd->d_fwd_amb.release();
+	if (rc == 0 && rd->has_amb) {
+		// which reads carry an ambiguity letter: the search sends only those through the ambiguity-aware kernels
+		std::vector<uint32_t> na((size_t)count);
+		rc = d_namb.download(na.data(), (size_t)count);
+		rd->h_read_amb.resize((size_t)count);
+		for (int64_t i = 0; i < count; i++)
+			rd->h_read_amb[(size_t)i] = na[(size_t)i] != 0;
+	}
 	if (rc == 0 && amb_count) {
 		amb_count->assign((size_t)count, 0);
 		rc = d_namb.download(amb_count->data(), (size_t)count);
