@@ -141,14 +141,15 @@ def main():
         from pangea_plus_amd.sharding import batch_first_read as sharding_first
         B = args.reads
         batches = []
-        for s in range(args.warmup + args.steps):
+        n_batches = min(args.warmup + args.steps, 8)  # a ring of distinct resident batches (1.1 GB each) bounds the memory
+        for s in range(n_batches):
             first = sharding_first(s, rank, world, B)
             reads = pg.Reads.from_synth(cfg, first, B)
             rdp = pg.Rdp.from_synth(cfg, first, B, db)
             batches.append((reads, rdp))
 
         def step(i):
-            reads, rdp = batches[i]
+            reads, rdp = batches[i % len(batches)]
             _capi.classify_consensus(db, reads, rdp, want_records=False, want_hits=False)
             return _capi.stage_times()
 
@@ -157,6 +158,10 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        # set-up, untimed like the rest of it: size the persistent workspaces and bring the GPU out of the idle clocks
+        # the host-side taxonomy binding leaves it in (a few pipeline passes; the W warm-up steps follow)
+        for _ in range(3):
+            step(0)
         for i in range(args.warmup):
             step(i)
         fence()
