@@ -1141,6 +1141,9 @@ struct SortWave {
 			uint64_t krm[kSortCap], kcnt[kSortCap]; // text-order keys of the agreement and token counts
 			uint32_t rm[kSortCap], sim[kSortCap];
 		} b;
+		struct { // the same per-rank inputs with 32-bit text-order keys (counts below 10^8), plus the chain pointers
+			uint32_t kcnt[kSortCap], sim_e[kSortCap], krm[kSortCap], rm[kSortCap], nxt[kSortCap];
+		} c;
 	};
 };
 
@@ -1315,13 +1318,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			recs[r].hit = -2;
 			recs[r].matches = 0;
 		}
-		if (cv.dbg != 4) {
-			const uint32_t k32 = mine ? dec_str_key32(rmv) : 0u; // >= 1 for any value
-			uint32_t kmax = k32;
+		const uint32_t k32 = mine ? dec_str_key32(rmv) : 0u; // >= 1 for any value
+		uint32_t kmax = k32;
 #pragma unroll
-			for (int m = 1; m < G; m <<= 1)
-				kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
-			const bool elig = mine && k32 == kmax;
+		for (int m = 1; m < G; m <<= 1)
+			kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
+		const bool elig = mine && k32 == kmax;
+		if (cv.dbg != 4) {
 			const uint32_t key2 = elig ? ((sim << 6) | (63u - rank)) + 1u : 0u;
 			uint32_t top = key2;
 #pragma unroll
@@ -1333,22 +1336,96 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 		}
 		if (odd_mask) {
+			const bool any_huge = __ballot(mine && (rmv >= 100000000u || ntok >= 100000000u || sim >= (1u << 25))) != 0ull;
 			lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
-			if (mine) {
-				sw->b.rm[slot0 + rank] = rmv;
-				sw->b.sim[slot0 + rank] = sim;
-				sw->b.krm[slot0 + rank] = dec_str_key(rmv);
-				sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
-			}
-			lds_fence();
-			if (li == 0 && n && slow && present) {
-				ArgmaxState am;
-				am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
-				for (uint32_t k = 0; k < n; k++)
-					am.step_keys((int32_t)(o + k), sw->b.rm[slot0 + k], sw->b.krm[slot0 + k], sw->b.kcnt[slot0 + k],
-						     sw->b.sim[slot0 + k]);
-				recs[r].hit = am.win;
-				recs[r].matches = (int32_t)am.maxrm;
+			if (any_huge) {
+				// counts of nine digits and more: 64-bit text keys, the literal walk
+				if (mine) {
+					sw->b.rm[slot0 + rank] = rmv;
+					sw->b.sim[slot0 + rank] = sim;
+					sw->b.krm[slot0 + rank] = dec_str_key(rmv);
+					sw->b.kcnt[slot0 + rank] = dec_str_key(ntok);
+				}
+				lds_fence();
+				if (li == 0 && n && slow && present) {
+					ArgmaxState am;
+					am.cursim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+					for (uint32_t k = 0; k < n; k++)
+						am.step_keys((int32_t)(o + k), sw->b.rm[slot0 + k], sw->b.krm[slot0 + k], sw->b.kcnt[slot0 + k],
+							     sw->b.sim[slot0 + k]);
+					recs[r].hit = am.win;
+					recs[r].matches = (int32_t)am.maxrm;
+				}
+			} else {
+				// Lineages of different depth.  When the first hit of the table already holds the largest agreement
+				// count, the walk of Consensus:186-204 reduces to a chain: the current choice h is replaced by the
+				// next hit j with the largest count that is not dominated by it (token-count text greater, or pident
+				// text greater), and after a replacement the remembered token count is j's own.  Every lane finds
+				// the successor of its own hit (one pass over the per-rank arrays), lane 0 follows the chain.
+				const uint32_t c32 = dec_str_key32(ntok);
+				if (mine) {
+					sw->c.kcnt[slot0 + rank] = c32;
+					sw->c.sim_e[slot0 + rank] = sim | (elig ? 0x80000000u : 0u);
+					sw->c.krm[slot0 + rank] = k32;
+					sw->c.rm[slot0 + rank] = rmv;
+				}
+				lds_fence();
+				if (n && slow && present) {
+					const bool top_is_max = (sw->c.sim_e[slot0] >> 31) != 0u;
+					const uint32_t init_sim = r == 0 ? cv.simrank_undef : cv.simrank_zero;
+					if (top_is_max) {
+						uint32_t nx = kNoRead;
+						for (uint32_t t = 0; t < n; t++) {
+							const uint32_t a = sw->c.kcnt[slot0 + t], b2 = sw->c.sim_e[slot0 + t];
+							const bool cand = mine && t > rank && (b2 >> 31) && (a > c32 || (b2 & 0x7FFFFFFFu) > sim);
+							nx = (cand && nx == kNoRead) ? t : nx;
+						}
+						if (mine)
+							sw->c.nxt[slot0 + rank] = nx;
+						lds_fence();
+						if (li == 0) {
+							uint32_t w = kNoRead;
+							if (sw->c.rm[slot0] > 0u) {
+								w = 0; // the first step takes hit 0 and its token count
+							} else {
+								// no agreement anywhere: the first hit that beats the initial (count "0", similarity) pair
+								for (uint32_t t = 0; t < n && w == kNoRead; t++)
+									if (sw->c.kcnt[slot0 + t] > 1u /* key of "0" */ || (sw->c.sim_e[slot0 + t] & 0x7FFFFFFFu) > init_sim)
+										w = t;
+							}
+							if (w != kNoRead) {
+								for (uint32_t nxw = sw->c.nxt[slot0 + w]; nxw != kNoRead; nxw = sw->c.nxt[slot0 + w])
+									w = nxw;
+								recs[r].hit = (int32_t)(o + w);
+								recs[r].matches = (int32_t)sw->c.rm[slot0 + w];
+							} else {
+								recs[r].hit = -1;
+								recs[r].matches = 0;
+							}
+						}
+					} else if (li == 0) {
+						// the literal walk on the 32-bit keys
+						uint32_t kr = 1u /* key of "0" */, mrm = 0, kc = 1u, cs = init_sim;
+						int32_t win = -1;
+						for (uint32_t k = 0; k < n; k++) {
+							const uint32_t vkrm = sw->c.krm[slot0 + k], vrm = sw->c.rm[slot0 + k], vkc = sw->c.kcnt[slot0 + k],
+								       vs = sw->c.sim_e[slot0 + k] & 0x7FFFFFFFu;
+							if (vkrm > kr) {
+								kr = vkrm;
+								mrm = vrm;
+								win = (int32_t)(o + k);
+								cs = vs;
+							}
+							if ((vkc > kc || cs < vs) && vrm == mrm) {
+								kc = vkc;
+								win = (int32_t)(o + k);
+								cs = vs;
+							}
+						}
+						recs[r].hit = win;
+						recs[r].matches = (int32_t)mrm;
+					}
+				}
 			}
 		}
 		lds_fence();

@@ -97,7 +97,8 @@ def test_pident_rounding_equals_printf(pg):
     assert bad == 0
 
 
-def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_bin):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_bin, variant):
     """Lineages of different depth inside one read's hits and agreement counts of two digits: the
     order-dependent selection of Consensus:186-204 has no closed form there (k_sort_consensus's literal walk)
     and Perl's text comparison of the counts ("10" lt "9") decides."""
@@ -109,17 +110,38 @@ def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_b
     out = []
     for line in (chain / "Tax_class" / "nodes.dmp").read_text().splitlines(True):
         cols = line.split("\t|\t")
-        if cols[2] == "species" and int(cols[0]) % 3 == 0:
-            cols[2] = "no rank"          # every third species loses its rank: shorter lineage text
-        if cols[2] == "genus" and int(cols[0]) % 5 == 0:
-            cols[2] = "subgenus"
+        t = int(cols[0])
+        if variant == 0:
+            if cols[2] == "species" and t % 3 == 0:
+                cols[2] = "no rank"          # every third species loses its rank: shorter lineage text
+            if cols[2] == "genus" and t % 5 == 0:
+                cols[2] = "subgenus"
+        elif variant == 1:
+            # depth varies at every level, so that a read's hits (one genus family) mix three or four depths
+            if cols[2] == "species" and t % 2 == 0:
+                cols[2] = "no rank"
+            if cols[2] == "family" and t % 3 == 0:
+                cols[2] = "no rank"
+            if cols[2] == "phylum" and t % 2 == 1:
+                cols[2] = "superphylum"
+        else:
+            # most species unranked, a few genera too: the top hit is often the shorter lineage
+            if cols[2] == "species" and t % 7 != 0:
+                cols[2] = "no rank"
+            if cols[2] == "genus" and t % 4 == 0:
+                cols[2] = "no rank"
         out.append("\t|\t".join(cols))
     (tdir / "nodes.dmp").write_text("".join(out))
     assert run_cmd([oracle_bin, "tax_class", "-c"], cwd=tdir)[0] == 0
     rows = (chain / "rdp.tsv").read_text().splitlines()
-    for i in range(0, len(rows), 4):     # every fourth read names its triplets three times over
+    for i in range(variant, len(rows), 4 - variant):     # some reads name their triplets three times over
         head, trip = rows[i].split("\t", 5)[:5], rows[i].split("\t", 5)[5]
         rows[i] = "\t".join(head + [trip, trip, trip])
+    for i in range(1, len(rows), 5):     # and some agree with nothing: every hit of the read counts 0 matches
+        head, trip = rows[i].split("\t", 5)[:5], rows[i].split("\t", 5)[5].split("\t")
+        for k in range(0, len(trip), 3):
+            trip[k] = "Zzz" + trip[k][::-1]
+        rows[i] = "\t".join(head + trip)
     (tmp_path / "rdp.tsv").write_text("\n".join(rows) + "\n")
     assert run_cmd([oracle_bin, "taxcollector", "-f", str(chain / "hits.tsv"), "-o", str(tmp_path / "hits_class.tsv"),
                     "-d", str(tdir)], timeout=600)[0] == 0
@@ -135,7 +157,7 @@ def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_b
     rdp = pg.Rdp.from_file(str(tmp_path / "rdp.tsv"), reads, db)
     hits, recs = _capi.classify_consensus(db, reads, rdp)
     assert _capi.consensus_format(db, reads, hits, recs) == want
-    assert int((recs["matches"] >= 10).sum()) > 0
+    assert int((recs["matches"] >= 10).sum()) > 0 and int(((recs["matches"] == 0) & (recs["hit"] >= 0)).sum()) > 100
     # and the file verb on the same tables
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
     assert (tmp_path / "c2.txt").read_bytes() == want
