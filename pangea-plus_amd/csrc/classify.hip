@@ -574,7 +574,7 @@ __device__ __forceinline__ void lds_fence()
 // its own half of the stage.  Longer reads keep the wavefront to themselves.
 // LISTED: the launch works on the reads named by rd.list (one search class of a mixed batch) instead of 0 .. n-1
 template <bool AMB, int NW, bool LISTED>
-__global__ __launch_bounds__(64 * kWavesPerBlock, NW <= 3 ? 4 : (NW <= 5 ? 3 : 2)) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
+__global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
 								      uint32_t *__restrict__ read_cnt,
 								      uint32_t *__restrict__ read_start)
 {
