@@ -373,3 +373,23 @@ def test_reads_of_200_to_512_bases_keep_their_flags_in_registers(pg, oracle_bin,
     want = out.read_bytes()
     assert len(want) > 100000
     assert hits.format(db, reads) == want
+
+
+def test_degenerate_inputs(pg, oracle_bin, tmp_path):
+    """Empty read files, reads shorter than a seed, a one-sequence database shorter than a word, a database with an
+    empty record: no crash, the same (mostly empty) table as the oracle."""
+    from pangea_plus_amd import _capi
+    db = tmp_path / "tiny.fa"
+    db.write_text(">gi|1|x|a|\nACGTACGTACGTACGTACGT\n>gi|2|x|empty|\n>gi|3|x|b|\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGAATTCCGGTTAACC" * 3 + "\n")
+    cases = {
+        "none": "",
+        "short": ">s1\nACGT\n>s2\nACGTACGTACGTAC\n>s3\n\n",
+        "mixed": ">m1\nACGTTGCAAGGCTTAACCGGATATCGCGAATTCCGGTTAACC\n>m2\nAC\n>m3\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGAATTCCGGTTAACC" * 2 + "\n",
+    }
+    for tag, text in cases.items():
+        rd = tmp_path / (tag + ".fa")
+        rd.write_text(text)
+        want = tmp_path / (tag + ".oracle.tsv")
+        assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)])[0] == 0
+        assert _blast_text(pg, db, rd, tmp_path, "deg_" + tag) == want.read_bytes(), tag
+    assert (tmp_path / "mixed.oracle.tsv").read_bytes()     # the mixed case does find hits
