@@ -676,13 +676,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 			uint32_t cnt = 0, lo = 0;
 			int strand = 0, qpos = 0;
 			uint32_t wl = 0, wr = 0; // the read's 16 bases from 13 left of the probe, and the 16 right of it
+			uint32_t flank_amb = 0;  // bit 0 / 1: an ambiguity letter in the read's left / right flank
 			if (pid < P && (my_rs == 0 || hasB)) {
 				strand = pid >= nps;
 				qpos = (pid - strand * nps) * kProbeStride;
 				const uint64_t *rw = (strand ? rd.rc : rd.fwd) + w0;
-				if (!AMB) {
-					wl = qpos >= kProbeStride ? window16(rw, qpos - kProbeStride) : 0u;
-					wr = window16(rw, qpos + kSeedK);
+				wl = qpos >= kProbeStride ? window16(rw, qpos - kProbeStride) : 0u;
+				wr = window16(rw, qpos + kSeedK);
+				if (AMB) {
+					// ambiguity letters in the read's own flanks switch the corresponding filter off for this probe
+					const uint64_t *ra0 = strand ? rd.rc_amb : rd.fwd_amb;
+					if (ra0) {
+						if (qpos >= kProbeStride && (window64(ra0 + w0, qpos - kProbeStride) & ((1ull << 26) - 1)))
+							flank_amb |= 1;
+						if (window64(ra0 + w0, qpos + kSeedK) & ((1ull << 24) - 1))
+							flank_amb |= 2;
+					}
 				}
 				bool ok = true;
 				if (AMB) {
@@ -708,7 +717,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 			const uint32_t excl = incl - cnt;
 			const uint32_t T = __shfl(incl, 63);
 			const uint32_t pbase_idx = lo - excl;                               // posting index of item k of this probe: pbase_idx + k
-			const uint32_t pmeta = (uint32_t)qpos | ((uint32_t)strand << 31);  // what an item needs to know of its probe
+			const uint32_t pmeta = (uint32_t)qpos | (flank_amb << 28) | ((uint32_t)strand << 31); // what an item needs to know of its probe
 			n_post += cnt;
 			if (db.dbg_stop == 1)
 				continue;
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				bool active[kDeal], tested[kDeal], keep[kDeal];
 				uint32_t pidx[kDeal], p[kDeal], sj[kDeal], s0[kDeal], s1[kDeal];
 				int o_strand[kDeal], o_qpos[kDeal], o_rs[kDeal];
-				uint32_t o_wl[kDeal], o_wr[kDeal];
+				uint32_t o_wl[kDeal], o_wr[kDeal], o_famb[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					const uint32_t item = it + 64 * u + lane;
@@ -735,7 +744,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 					pidx[u] = __shfl(pbase_idx, o) + key;
 					const uint32_t m = __shfl(pmeta, o);
 					o_strand[u] = (int)(m >> 31);
-					o_qpos[u] = (int)(m & 0x7FFFFFFFu);
+					o_qpos[u] = (int)(m & 0x0FFFFFFFu);
+					o_famb[u] = AMB ? (m >> 28) & 3u : 0u;
 					o_rs[u] = o / LPR;
 					o_wl[u] = __shfl(wl, o);
 					o_wr[u] = __shfl(wr, o);
@@ -746,10 +756,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				for (int u = 0; u < kDeal; u++) {
 					raw[u] = 0u;
 					ctx[u] = make_uint2(0u, 0u);
-					if (AMB) {
-						if (active[u])
-							raw[u] = db.postings[pidx[u]];
-					} else if (active[u]) {
+					if (active[u]) {
 						// posting and its context in one 12-byte record
 						const uint3 rec = db.post_ctx[pidx[u]];
 						raw[u] = rec.x;
@@ -759,19 +766,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				// stage 2: the 13 database bases left and the 12 right of the 16-mer (post_ctx, fetched beside
 				// the posting) against the read's (extracted once per probe, handed over by its lane)
 				uint32_t xl[kDeal], xr[kDeal];
+				bool lknown[kDeal], rknown[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
 					p[u] = raw[u] & 0x7FFFFFFFu;
 					keep[u] = active[u];
 					tested[u] = false;
 					xl[u] = xr[u] = 0;
-					if (!AMB && active[u]) {
-						if (o_qpos[u] >= kProbeStride) {
+					lknown[u] = rknown[u] = false;
+					if (active[u]) {
+						// flanks with an ambiguity letter (database: bit 31 of the context; read: the probe's flags)
+						// are unknown: the filters then assume the most they could match
+						const bool db_clean = !AMB || !(ctx[u].x >> 31);
+						const uint32_t fa = AMB ? o_famb[u] : 0u; // reads of the unambiguous classes have clean flanks
+						lknown[u] = db_clean && !(fa & 1u) && o_qpos[u] >= kProbeStride;
+						rknown[u] = db_clean && !(fa & 2u);
+						if (lknown[u]) {
 							// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
 							tested[u] = !(raw[u] >> 31);
 							xl[u] = ctx[u].x ^ o_wl[u];
 						}
-						xr[u] = ctx[u].y ^ o_wr[u];
+						if (rknown[u])
+							xr[u] = ctx[u].y ^ o_wr[u];
 					}
 				}
 				// stage 3: la / ra = matching bases immediately left / right of the 16-mer (capped at 13 / 12,
@@ -781,11 +797,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				// follow on the diagonal's flags.)
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
-					if (!AMB && keep[u]) {
+					if (keep[u]) {
 						const uint32_t ml = (xl[u] | (xl[u] >> 1)) & 0x01555555u; // bases 0..12
 						const uint32_t mr = (xr[u] | (xr[u] >> 1)) & 0x00555555u; // bases 0..11
-						int la = o_qpos[u] >= kProbeStride ? (ml ? 12 - ((31 - __clz((int)ml)) >> 1) : kProbeStride) : 0;
-						int ra = mr ? (__ffs((int)mr) - 1) >> 1 : kWord - kSeedK;
+						int la = o_qpos[u] >= kProbeStride ? (lknown[u] ? (ml ? 12 - ((31 - __clz((int)ml)) >> 1) : kProbeStride) : kProbeStride) : 0;
+						int ra = rknown[u] ? (mr ? (__ffs((int)mr) - 1) >> 1 : kWord - kSeedK) : kWord - kSeedK;
 						if (tested[u] && la == kProbeStride)
 							keep[u] = false;
 						const int room = (o_rs[u] ? LB : LA) - o_qpos[u] - kSeedK;
@@ -1477,7 +1493,7 @@ static DbView db_view(const pgx_db *db)
 	v.seq_off = db->d_seq_off.data();
 	v.blk_subj = db->d_blk_subj.data();
 	v.blk_info = db->d_blk_info.data();
-	v.post_ctx = db->has_amb ? nullptr : db->d_post_ctx.data();
+	v.post_ctx = db->d_post_ctx.data();
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;

@@ -236,15 +236,24 @@ __global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, 
 // post_ctx[i] = posting i with the database around it, in index order: x = the posting, y = the 16 bases from 13 left of the 16-mer,
 // z = the 16 bases right of it.  k_seed_extend's duplicate and short-run filters read them from this
 // contiguous stream instead of fetching a random database line per posting.
-__global__ void k_post_ctx(const uint64_t *__restrict__ words, const uint32_t *__restrict__ postings, uint64_t n,
-			   uint3 *__restrict__ ctx)
+// Bit 31 of y (a base of the 16-mer itself, which the filters never look at) is set when any of the 41 bases from 13
+// left of the 16-mer to 12 right of it is an ambiguity letter: the filters then leave the posting alone.
+__global__ void k_post_ctx(const uint64_t *__restrict__ words, const uint64_t *__restrict__ amb, const uint32_t *__restrict__ postings,
+			   uint64_t n, uint3 *__restrict__ ctx)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
 		const uint32_t raw = postings[i];
 		const int64_t p = (int64_t)(raw & 0x7FFFFFFFu);
-		ctx[i] = make_uint3(raw, window16(words, p - kProbeStride), window16(words, p + kSeedK));
+		uint32_t y = window16(words, p - kProbeStride) & 0x7FFFFFFFu;
+		if (amb) {
+			// spaced flags: 32 bases from p-13 (all of them count: up to p+18), then the 9 bases p+19 .. p+27
+			const uint64_t a0 = window64(amb, p - kProbeStride), a1 = window64(amb, p + 19);
+			if (a0 | (a1 & ((1ull << 18) - 1)))
+				y |= 0x80000000u;
+		}
+		ctx[i] = make_uint3(raw, y, window16(words, p + kSeedK));
 	}
 }
 
@@ -448,12 +457,10 @@ int db_build_index(pgx_db *db)
 	PGX_HIP(hipGetLastError());
 	keys_in.release();
 	vals_in.release();
-	if (!db->has_amb) {
-		PGX_TRY(db->d_post_ctx.alloc(n));
-		hipLaunchKernelGGL(k_post_ctx, dim3(grid), dim3(256), 0, 0, db->d_words.data(), db->d_postings.data(), n,
-				   db->d_post_ctx.data());
-		PGX_HIP(hipGetLastError());
-	}
+	PGX_TRY(db->d_post_ctx.alloc(n));
+	hipLaunchKernelGGL(k_post_ctx, dim3(grid), dim3(256), 0, 0, db->d_words.data(), db->has_amb ? db->d_amb.data() : (const uint64_t *)nullptr,
+			   db->d_postings.data(), n, db->d_post_ctx.data());
+	PGX_HIP(hipGetLastError());
 	// exclusive scan of the counts in place -> bucket offsets; the extra last element becomes n.
 	// (Own three-pass scan with 64-bit indexing: the table has 2^32 + 1 entries at full size, and
 	// rocprim::exclusive_scan returned a doubled prefix for the last 4 097 of them.)
@@ -1402,8 +1409,7 @@ int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
 	add("blk_subj", db->d_blk_subj.data(), db->d_blk_subj.bytes());
 	add("bucket_off", db->d_bucket_off.data(), db->d_bucket_off.bytes());
 	add("postings", db->d_postings.data(), db->d_postings.bytes());
-	if (!db->has_amb)
-		add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
+	add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
 	return n;
 }
 
@@ -1431,7 +1437,7 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 		rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
 	if (rc == 0)
 		rc = db->d_postings.alloc(db->n_postings ? (size_t)db->n_postings : 1);
-	if (rc == 0 && !db->has_amb)
+	if (rc == 0)
 		rc = db->d_post_ctx.alloc(db->n_postings ? (size_t)db->n_postings : 1);
 	if (rc < 0) {
 		delete db;
