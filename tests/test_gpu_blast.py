@@ -269,7 +269,7 @@ def test_very_long_query_and_thousands_of_hits(pg, oracle_bin, tmp_path):
     assert _blast_text(pg, db2, rd2, tmp_path, "many") == want2.read_bytes()
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303])
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_FUZZ_SEEDS", "101,202,303").split(",")])
 def test_random_mixtures_match_oracle(pg, oracle_bin, tmp_path, seed):
     """Fuzz: databases of 40-3 000-base sequences (repeats, N runs, IUPAC letters, near-identical copies), reads of
     20-320 bases from either strand with substitutions and Ns: short reads (< 28: no hit possible), dense (<= 192) and
