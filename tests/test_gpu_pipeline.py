@@ -97,7 +97,7 @@ def test_pident_rounding_equals_printf(pg):
     assert bad == 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [int(x) for x in os.environ.get("PGX_RAGGED_VARIANTS", "0,1,2,3").split(",")])
 def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_bin, variant):
     """Lineages of different depth inside one read's hits and agreement counts of two digits: the
     order-dependent selection of Consensus:186-204 has no closed form there (k_sort_consensus's literal walk)
@@ -124,17 +124,23 @@ def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_b
                 cols[2] = "no rank"
             if cols[2] == "phylum" and t % 2 == 1:
                 cols[2] = "superphylum"
-        else:
+        elif variant == 2:
             # most species unranked, a few genera too: the top hit is often the shorter lineage
             if cols[2] == "species" and t % 7 != 0:
                 cols[2] = "no rank"
             if cols[2] == "genus" and t % 4 == 0:
                 cols[2] = "no rank"
+        else:
+            # seeded random: any ranked node below the domain loses or changes its rank with its own probability
+            import random
+            rr = random.Random(variant * 1000003 + t)
+            if cols[2] in ("phylum", "class", "order", "family", "genus", "species") and rr.random() < 0.1 * (1 + variant % 5):
+                cols[2] = rr.choice(["no rank", "no rank", "subgenus", "tribe", "species group"])
         out.append("\t|\t".join(cols))
     (tdir / "nodes.dmp").write_text("".join(out))
     assert run_cmd([oracle_bin, "tax_class", "-c"], cwd=tdir)[0] == 0
     rows = (chain / "rdp.tsv").read_text().splitlines()
-    for i in range(variant, len(rows), 4 - variant):     # some reads name their triplets three times over
+    for i in range(variant % 4, len(rows), 4 - variant % 3):     # some reads name their triplets three times over
         head, trip = rows[i].split("\t", 5)[:5], rows[i].split("\t", 5)[5]
         rows[i] = "\t".join(head + [trip, trip, trip])
     for i in range(1, len(rows), 5):     # and some agree with nothing: every hit of the read counts 0 matches
