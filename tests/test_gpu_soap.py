@@ -57,9 +57,10 @@ def test_soap_rows_equal_the_reference_binary(pg, gold, oracle_bin, tmp_path):
             assert a == b
 
 
-def test_soap_short_reads_and_seeded_mismatches_match_oracle(pg, oracle_bin, tmp_path):
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_SOAP_SEEDS", "3").split(",")])
+def test_soap_short_reads_and_seeded_mismatches_match_oracle(pg, oracle_bin, tmp_path, seed):
     import random
-    rng = random.Random(3)
+    rng = random.Random(seed)
     shape = ["--n-seq", "300", "--seq-len", "700", "--n-genus", "12"]
     db = tmp_path / "db.fa"
     assert run_cmd([oracle_bin, "synth", "db", "--out", str(db)] + shape)[0] == 0
