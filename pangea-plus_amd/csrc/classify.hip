@@ -341,7 +341,7 @@ struct WaveLds {
 	// queued candidates: posting, strand << 31 | tested << 30 | read slot << 29 | owns-diagonal << 28 | qpos, and the
 	// subject found while filtering
 	uint32_t qp[kQueue], qmeta[kQueue], qsubj[kQueue], qs0[kQueue], qs1[kQueue];
-	uint32_t diag[2][kDiagSlots];        // per read of the pair: diagonals already owned by a queued candidate
+	uint32_t diag[2][2][kDiagSlots / 2]; // per read of the pair and strand: diagonals already owned by a queued candidate
 	unsigned int n[2];                   // staged hits per read slot
 	unsigned int direct[2];              // hits that found the stage full and went straight to the overflow table
 };
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 		if (RPW == 2) {
 #pragma unroll
 			for (int k = 0; k < 2 * kDiagSlots / 64; k++)
-				(&st->diag[0][0])[k * 64 + lane] = kNoDiag;
+				(&st->diag[0][0][0])[k * 64 + lane] = kNoDiag;
 		}
 		lds_fence();
 
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				bool lknown[kDeal], rknown[kDeal];
 #pragma unroll
 				for (int u = 0; u < kDeal; u++) {
-					p[u] = raw[u] & 0x7FFFFFFFu;
+					p[u] = raw[u];
 					keep[u] = active[u];
 					tested[u] = false;
 					xl[u] = xr[u] = 0;
@@ -782,8 +782,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 						lknown[u] = db_clean && !(fa & 1u) && o_qpos[u] >= kProbeStride;
 						rknown[u] = db_clean && !(fa & 2u);
 						if (lknown[u]) {
-							// a posting within 13 bases of its sequence's start (bit 31) is never "tested"
-							tested[u] = !(raw[u] >> 31);
+							// a posting within 13 bases of its sequence's start (bit 30 of the context) is never "tested"
+							tested[u] = !((ctx[u].x >> 30) & 1u);
 							xl[u] = ctx[u].x ^ o_wl[u];
 						}
 						if (rknown[u])
@@ -847,10 +847,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 						const int64_t d0 = (int64_t)p[u] - o_qpos[u];
 						const int Lr = o_rs[u] ? LB : LA;
 						if (d0 >= (int64_t)s0[u] && d0 + Lr <= (int64_t)s1[u]) {
-							const uint32_t key = (uint32_t)d0 | ((uint32_t)o_strand[u] << 31);
-							const uint32_t h0 = (key * 0x9E3779B1u) >> 25;
+							const uint32_t key = (uint32_t)d0; // positions are 32-bit: one table per strand
+							const uint32_t h0 = (key * 0x9E3779B1u) >> 26;
 							for (int t = 0; t < kDiagProbes; t++) {
-								const uint32_t old = atomicCAS(&st->diag[o_rs[u]][(h0 + t) & (kDiagSlots - 1)], kNoDiag, key);
+								const uint32_t old = atomicCAS(&st->diag[o_rs[u]][o_strand[u]][(h0 + t) & (kDiagSlots / 2 - 1)], kNoDiag, key);
 								if (old == kNoDiag) {
 									claimed[u] = true;
 									break;

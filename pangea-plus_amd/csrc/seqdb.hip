@@ -215,38 +215,41 @@ __global__ void k_blk_subj(const uint32_t *__restrict__ seq_off, uint32_t n_seq,
 	blk[b] = lo;
 }
 
-// posting = position | near_start << 31, where near_start marks the first 13 positions of every sequence:
-// there the probe 13 bases to the left lies (partly) in the previous sequence, so the index-side duplicate
-// filter of k_seed_extend must not trust it
-__global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, int bits, const uint32_t *__restrict__ seq_off,
-			    const uint32_t *__restrict__ blk_subj, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// posting = position of the 16-mer in the concatenated database (full 32 bits: databases up to 4.29 Gbp)
+__global__ void k_seed_keys(const uint64_t *__restrict__ words, uint64_t n_pos, int bits, uint32_t *__restrict__ keys,
+			    uint32_t *__restrict__ vals)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n_pos; i += stride) {
 		keys[i] = seed_bucket(kmer16(words, (int64_t)i), bits);
-		uint32_t s = blk_subj[i >> kBlkShift];
-		while (seq_off[s + 1] <= i)
-			s++;
-		const uint32_t near_start = (uint32_t)(i - seq_off[s]) < (uint32_t)kProbeStride;
-		vals[i] = (uint32_t)i | (near_start << 31);
+		vals[i] = (uint32_t)i;
 	}
 }
 
 // post_ctx[i] = posting i with the database around it, in index order: x = the posting, y = the 16 bases from 13 left of the 16-mer,
 // z = the 16 bases right of it.  k_seed_extend's duplicate and short-run filters read them from this
 // contiguous stream instead of fetching a random database line per posting.
-// Bit 31 of y (a base of the 16-mer itself, which the filters never look at) is set when any of the 41 bases from 13
-// left of the 16-mer to 12 right of it is an ambiguity letter: the filters then leave the posting alone.
+// The top bits of y belong to bases of the 16-mer itself, which the filters never look at; they carry two flags:
+// bit 31: one of the 41 bases from 13 left of the 16-mer to 12 right of it is an ambiguity letter (the filters then
+//         leave the posting alone);
+// bit 30: the posting lies within 13 bases of its sequence's start: the probe 13 bases to the left lies (partly) in
+//         the previous sequence, so the duplicate filter must not trust it.
 __global__ void k_post_ctx(const uint64_t *__restrict__ words, const uint64_t *__restrict__ amb, const uint32_t *__restrict__ postings,
-			   uint64_t n, uint3 *__restrict__ ctx)
+			   const uint32_t *__restrict__ seq_off, const uint32_t *__restrict__ blk_subj, uint64_t n,
+			   uint3 *__restrict__ ctx)
 {
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n; i += stride) {
 		const uint32_t raw = postings[i];
-		const int64_t p = (int64_t)(raw & 0x7FFFFFFFu);
-		uint32_t y = window16(words, p - kProbeStride) & 0x7FFFFFFFu;
+		const int64_t p = (int64_t)raw;
+		uint32_t y = window16(words, p - kProbeStride) & 0x3FFFFFFFu;
+		uint32_t sj = blk_subj[raw >> kBlkShift];
+		while (seq_off[sj + 1] <= raw)
+			sj++;
+		if (raw - seq_off[sj] < (uint32_t)kProbeStride)
+			y |= 0x40000000u;
 		if (amb) {
 			// spaced flags: 32 bases from p-13 (all of them count: up to p+18), then the 9 bases p+19 .. p+27
 			const uint64_t a0 = window64(amb, p - kProbeStride), a1 = window64(amb, p + 19);
@@ -400,7 +403,7 @@ __global__ void k_index_check(const uint32_t *__restrict__ bucket_off, uint64_t 
 			atomicMax(&bad[3], (unsigned long long)k);
 		}
 	for (uint64_t k = i; k < n_post; k += stride)
-		if ((postings[k] & 0x7FFFFFFFu) + (uint64_t)kSeedK > n_bases)
+		if ((uint64_t)postings[k] + (uint64_t)kSeedK > n_bases)
 			atomicAdd(&bad[1], 1ull);
 }
 
@@ -443,8 +446,7 @@ int db_build_index(pgx_db *db)
 	PGX_TRY(keys_out.alloc(n));
 	PGX_TRY(vals_in.alloc(n));
 	int grid = (int)std::min<uint64_t>((n + 255) / 256, 256 * 32);
-	hipLaunchKernelGGL(k_seed_keys, dim3(grid), dim3(256), 0, 0, db->d_words.data(), n, db->index_bits,
-			   db->d_seq_off.data(), db->d_blk_subj.data(), keys_in.data(), vals_in.data());
+	hipLaunchKernelGGL(k_seed_keys, dim3(grid), dim3(256), 0, 0, db->d_words.data(), n, db->index_bits, keys_in.data(), vals_in.data());
 	PGX_HIP(hipGetLastError());
 	size_t tmp_bytes = 0;
 	PGX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.data(), keys_out.data(), vals_in.data(),
@@ -459,7 +461,7 @@ int db_build_index(pgx_db *db)
 	vals_in.release();
 	PGX_TRY(db->d_post_ctx.alloc(n));
 	hipLaunchKernelGGL(k_post_ctx, dim3(grid), dim3(256), 0, 0, db->d_words.data(), db->has_amb ? db->d_amb.data() : (const uint64_t *)nullptr,
-			   db->d_postings.data(), n, db->d_post_ctx.data());
+			   db->d_postings.data(), db->d_seq_off.data(), db->d_blk_subj.data(), n, db->d_post_ctx.data());
 	PGX_HIP(hipGetLastError());
 	// exclusive scan of the counts in place -> bucket offsets; the extra last element becomes n.
 	// (Own three-pass scan with 64-bit indexing: the table has 2^32 + 1 entries at full size, and
@@ -522,8 +524,8 @@ static int db_upload_offsets(pgx_db *db)
 int db_upload_and_index(pgx_db *db)
 {
 	PGX_TRY(require_device());
-	if (db->n_bases >= (1ll << 31) - 64)
-		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 31-bit position limit of this build",
+	if (db->n_bases >= (1ll << 32) - 64)
+		return fail(PGX_E_LIMIT, "database of %lld bases exceeds the 32-bit position limit of this build",
 			    (long long)db->n_bases);
 	size_t nw = ((size_t)db->n_bases + 31) / 32;
 	PGX_TRY(db->d_words.alloc(nw, 24, 24, true));
@@ -1282,9 +1284,9 @@ int pgx_db_from_synth(const pgx_synth_cfg *cfg, pgx_db **out)
 	pgx_db *db = new pgx_db();
 	db->n_seq = cfg->n_seq;
 	db->n_bases = cfg->n_seq * (int64_t)cfg->seq_len;
-	if (db->n_bases >= (1ll << 31) - 64) {
+	if (db->n_bases >= (1ll << 32) - 64) {
 		delete db;
-		return fail(PGX_E_LIMIT, "synthetic database exceeds the 31-bit position limit");
+		return fail(PGX_E_LIMIT, "synthetic database exceeds the 32-bit position limit");
 	}
 	db->h_seq_off.resize((size_t)db->n_seq + 1);
 	for (int64_t i = 0; i <= db->n_seq; i++)

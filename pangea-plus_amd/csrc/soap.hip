@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_soap_search(SoapView db, const uint64_t
 					const int o_strand = __shfl(strand, o), o_sidx = __shfl(sidx, o);
 					if (!active)
 						continue;
-					const uint32_t p = db.postings[o_lo + (key - o_excl)] & 0x7FFFFFFFu;
+					const uint32_t p = db.postings[o_lo + (key - o_excl)];
 					const uint64_t *rw = (o_strand ? rc : fwd) + w0;
 					const int seed_off = exact_mode ? so[o_sidx] : 0;
 					if (p < (uint32_t)seed_off)

@@ -99,3 +99,33 @@ def test_full_size_properties(full):
     tail = h[off[n // 2]:].copy()
     tail["read"] -= n // 2
     assert (tail == h2).all()
+
+
+def test_three_gigabase_database_uses_32_bit_positions(oracle_bin, tmp_path):
+    """3.0 Gbp (2 000 001 x 1 500 bp): database positions above 2^31.  Reads are drawn from the whole database, so about a
+    third of the hits lie in the upper part; -outfmt 6 table and consensus text against the oracle chain, byte for byte."""
+    import pangea_plus_amd as pg
+    from pangea_plus_amd import _capi
+    pg.init(0)
+    cfg = pg.SynthCfg.default(n_seq=2_000_001, n_genus=60_000)
+    _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), str(tmp_path).encode()))
+    pg.TaxDb.create(str(tmp_path))
+    db = pg.Db.from_synth(cfg)
+    assert db.shape()[1] == 2_000_001 * 1500 > 2 ** 31
+    db.bind_taxonomy(pg.TaxDb.open(str(tmp_path)))
+    first, n = 777_000, 1000
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    oc = OCfg(cfg.seed, cfg.n_seq, cfg.seq_len, cfg.n_genus, cfg.read_seed, cfg.read_len)
+    res = ORes()
+    lib.o_bench_chain_files.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p]
+    hits_p, cons_p = str(tmp_path / "o_hits.tsv"), str(tmp_path / "o_cons.txt")
+    assert lib.o_bench_chain_files(C.byref(oc), first, n, min(os.cpu_count() or 1, 16), str(tmp_path).encode(), C.byref(res),
+                                   hits_p.encode(), cons_p.encode()) == 0
+    reads = pg.Reads.from_synth(cfg, first, n)
+    rdp = pg.Rdp.from_synth(cfg, first, n, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    h = hits.to_numpy()
+    assert (h["subject"] >= 1_431_656).sum() > len(h) // 5      # subjects whose bases lie above 2^31
+    assert res.hits == len(hits) > 10000
+    assert hits.format(db, reads) == open(hits_p, "rb").read()
+    assert _capi.consensus_format(db, reads, hits, recs) == open(cons_p, "rb").read()
