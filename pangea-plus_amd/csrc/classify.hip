@@ -30,6 +30,7 @@ struct DbView {
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
 	const uint4 *blk_info;
 	const uint3 *post_ctx;
+	const uint32_t *amb_blk; // one bit per 512-base block with an ambiguity letter (null: the database has none)
 	uint32_t n_seq;
 	int bits;
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
@@ -410,7 +411,17 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	D.ra = ra;
 	D.dbw = db.words;
 	D.dba = db.amb;
+
 	D.dstart = (int64_t)p - qp;
+	if (AMB && db.amb && db.amb_blk) {
+		// most diagonals touch no block with an ambiguity letter: they skip the flag words of the database
+		const int64_t a = D.dstart > 0 ? D.dstart : 0, b = D.dstart + L - 1;
+		uint32_t any = 0;
+		for (int64_t blk = a >> kBlkShift; blk <= (b >> kBlkShift); blk++)
+			any |= (db.amb_blk[blk >> 5] >> (blk & 31)) & 1u;
+		if (!any)
+			D.dba = nullptr;
+	}
 	int64_t lo64 = (int64_t)s_start - D.dstart, hi64 = (int64_t)s_end - D.dstart;
 	D.lo = lo64 > 0 ? (int)lo64 : 0;
 	D.hi = hi64 < L ? (int)hi64 : L;
@@ -1494,6 +1505,7 @@ static DbView db_view(const pgx_db *db)
 	v.blk_subj = db->d_blk_subj.data();
 	v.blk_info = db->d_blk_info.data();
 	v.post_ctx = db->d_post_ctx.data();
+	v.amb_blk = db->has_amb && !getenv("PGX_NO_AMB_BLK") ? db->d_amb_blk.data() : nullptr; // (switch: measurement aid)
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;

@@ -29,6 +29,7 @@ struct pgx_db {
 	pgx::DevBuf<uint64_t> d_words, d_amb;
 	pgx::DevBuf<uint32_t> d_seq_off, d_blk_subj;
 	pgx::DevBuf<uint4> d_blk_info; // per 512-base block: subject, its start, its end, the next subject's end
+	pgx::DevBuf<uint32_t> d_amb_blk; // databases with ambiguity letters: one bit per 512-base block that holds one
 	int index_bits = 0;
 	int64_t n_postings = 0;
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;

@@ -495,9 +495,38 @@ __global__ void k_blk_info(const uint32_t *__restrict__ seq_off, uint32_t n_seq,
 	info[b] = make_uint4(s, seq_off[s], seq_off[s1], seq_off[s2]);
 }
 
+// bit b of amb_blk: block b (512 bases = 16 flag words) holds an ambiguity letter.  Diagonals that touch no such
+// block build their flags without reading the ambiguity words at all.
+__global__ void k_amb_blocks(const uint64_t *__restrict__ amb, uint64_t n_words, uint64_t n_blk, uint32_t *__restrict__ bits)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one 32-block word of the bitmap per thread
+	if (w * 32 >= n_blk)
+		return;
+	uint32_t v = 0;
+	for (int k = 0; k < 32; k++) {
+		const uint64_t b = w * 32 + k;
+		uint64_t any = 0;
+		for (int j = 0; j < 16; j++) {
+			const uint64_t i = b * 16 + j;
+			if (i < n_words)
+				any |= amb[i];
+		}
+		if (any)
+			v |= 1u << k;
+	}
+	bits[w] = v;
+}
+
 int db_build_blk_info(pgx_db *db)
 {
 	const uint64_t n_blk = ((uint64_t)db->n_bases >> kBlkShift) + 2;
+	if (db->has_amb) {
+		const uint64_t n_bm = (n_blk + 31) / 32 + 1;
+		PGX_TRY(db->d_amb_blk.alloc(n_bm, 0, 0, true));
+		hipLaunchKernelGGL(k_amb_blocks, dim3((unsigned)((n_bm + 255) / 256)), dim3(256), 0, 0, db->d_amb.data(),
+				   ((uint64_t)db->n_bases + 31) / 32, n_blk, db->d_amb_blk.data());
+		PGX_HIP(hipGetLastError());
+	}
 	PGX_TRY(db->d_blk_info.alloc(n_blk));
 	if (db->n_seq > 0) {
 		hipLaunchKernelGGL(k_blk_info, dim3((unsigned)((n_blk + 255) / 256)), dim3(256), 0, 0, db->d_seq_off.data(),
