@@ -163,7 +163,9 @@ def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_b
     rdp = pg.Rdp.from_file(str(tmp_path / "rdp.tsv"), reads, db)
     hits, recs = _capi.classify_consensus(db, reads, rdp)
     assert _capi.consensus_format(db, reads, hits, recs) == want
-    assert int((recs["matches"] >= 10).sum()) > 0 and int(((recs["matches"] == 0) & (recs["hit"] >= 0)).sum()) > 100
+    if variant < 3:   # the hand-made variants are built to reach two-digit counts; the random ones need not
+        assert int((recs["matches"] >= 10).sum()) > 0
+    assert int(((recs["matches"] == 0) & (recs["hit"] >= 0)).sum()) > 100
     # and the file verb on the same tables
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
     assert (tmp_path / "c2.txt").read_bytes() == want
