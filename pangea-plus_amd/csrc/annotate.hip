@@ -9,6 +9,7 @@
 //                           logic over the two files is control flow on ids (host); agreement counting and
 //                           the order-dependent arg-max run on the device (consensus_core.hpp)
 #include <algorithm>
+#include <chrono>
 #include <map>
 
 #include "bitops.hpp"
@@ -872,6 +873,12 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 	if (rc < 0)
 		return done(rc);
 	log.s += "\nLoading input files...\n"; // Consensus:19
+	const bool trace = getenv("PGX_TRACE") != nullptr;
+	auto t_now = [] { return std::chrono::steady_clock::now(); };
+	auto t_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+		return std::chrono::duration<double, std::milli>(b - a).count();
+	};
+	const auto t0 = t_now();
 	bool ok;
 	std::string bt = read_text_file(b, &ok);
 	if (!ok) {
@@ -893,67 +900,146 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 	}
 	log.printf("%s\n", o); // Consensus:51
 
+	const auto t1 = t_now();
 	// ---- BLAST(+lineage) table: id, lineage tokens, similarity text per line (Consensus:110-122)
 	std::unordered_map<std::string, uint32_t> tmap;
 	std::vector<std::string> ttext;
 	intern_into(tmap, ttext, "");
-	// Nothing is copied per line: lines and their id are spans of the file text; the lineage column is tokenised once
-	// per DISTINCT lineage text (a hit table names a few hundred thousand lineages millions of times) and the
-	// similarity column is ranked once per distinct text.
+	// Nothing is copied per line: lines and their id are spans of the file text.  Pass A (all host cores, contiguous
+	// pieces of the file): line boundaries, the first three columns of split(/\t\t|\t/) and a 64-bit hash of the
+	// lineage and similarity texts.  Pass B (one thread): the lineage column is tokenised once per DISTINCT text (a
+	// hit table names a few hundred thousand lineages millions of times) and the similarity column ranked once per
+	// distinct text; equal hashes are confirmed by comparing the texts.
 	struct Span {
 		size_t s, n;
 	};
+	struct LineInfo {
+		size_t s;
+		uint32_t n, id_n, lin_s, lin_n, sim_s, sim_n; // column offsets are relative to the line start
+		uint64_t lin_h, sim_h;
+	};
+	auto fnv64 = [](const char *p, size_t n) {
+		uint64_t h = 1469598103934665603ull;
+		for (size_t i = 0; i < n; i++)
+			h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+		return h;
+	};
+	const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, bt.size() / (4u << 20) + 1));
+	std::vector<std::vector<LineInfo>> part(workers);
+	{
+		// piece w = [cut[w], cut[w+1]) where every cut is a line start
+		std::vector<size_t> cut(workers + 1, bt.size());
+		cut[0] = 0;
+		for (unsigned w = 1; w < workers; w++) {
+			size_t c = bt.size() * w / workers;
+			const char *nl = c < bt.size() ? (const char *)memchr(bt.data() + c, '\n', bt.size() - c) : nullptr;
+			cut[w] = nl ? (size_t)(nl - bt.data()) + 1 : bt.size();
+		}
+		auto scan = [&](unsigned w) {
+			std::vector<LineInfo> &out = part[w];
+			out.reserve((cut[w + 1] - cut[w]) / 60 + 16);
+			for (size_t s = cut[w]; s < cut[w + 1];) {
+				const char *nl = (const char *)memchr(bt.data() + s, '\n', bt.size() - s);
+				const size_t e = nl ? (size_t)(nl - bt.data()) : bt.size();
+				const char *ln = bt.data() + s;
+				const size_t n = e - s;
+				// split(/\t\t|\t/): fields 0, 1, 2 in place (a trailing empty field does not exist)
+				Span f[3] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+				int nf = 0;
+				size_t a = 0, i = 0;
+				while (i < n && nf < 3) {
+					if (ln[i] == '\t') {
+						f[nf++] = { a, i - a };
+						i += (i + 1 < n && ln[i + 1] == '\t') ? 2 : 1;
+						a = i;
+					} else {
+						i++;
+					}
+				}
+				if (nf < 3 && n > 0 && a < n)
+					f[nf++] = { a, n - a };
+				LineInfo li;
+				li.s = s;
+				li.n = (uint32_t)n;
+				li.id_n = (uint32_t)f[0].n;
+				li.lin_s = (uint32_t)f[1].s;
+				li.lin_n = (uint32_t)f[1].n;
+				li.sim_s = (uint32_t)f[2].s;
+				li.sim_n = (uint32_t)f[2].n;
+				li.lin_h = fnv64(ln + f[1].s, f[1].n);
+				li.sim_h = fnv64(ln + f[2].s, f[2].n);
+				out.push_back(li);
+				s = e + 1;
+			}
+		};
+		if (workers == 1) {
+			scan(0);
+		} else {
+			std::vector<std::thread> th;
+			for (unsigned w = 0; w < workers; w++)
+				th.emplace_back(scan, w);
+			for (auto &t : th)
+				t.join();
+		}
+	}
+	size_t n_lines = 0;
+	for (auto &v : part)
+		n_lines += v.size();
 	std::vector<Span> bline, bid;
+	bline.reserve(n_lines);
+	bid.reserve(n_lines);
 	std::vector<uint32_t> tok_off(1, 0), tok;
+	tok.reserve(n_lines * 14);
 	std::vector<std::string> tk;
-	std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> lin_memo; // lineage text -> (first token, count) in lin_tok
+	struct Memo {
+		size_t s;
+		uint32_t n, first, count; // representative text (file offset, length), its tokens in lin_tok
+	};
+	std::unordered_multimap<uint64_t, Memo> lin_memo;
 	std::vector<uint32_t> lin_tok;
-	std::unordered_map<std::string, uint32_t> sim_id; // similarity text -> id
+	struct SimMemo {
+		size_t s;
+		uint32_t n, id;
+	};
+	std::unordered_multimap<uint64_t, SimMemo> sim_memo;
 	std::vector<std::string> sim_text;
 	std::vector<uint32_t> line_simid;
-	std::string key;
-	for (size_t s = 0; s < bt.size();) {
-		const char *nl = (const char *)memchr(bt.data() + s, '\n', bt.size() - s);
-		const size_t e = nl ? (size_t)(nl - bt.data()) : bt.size();
-		const char *ln = bt.data() + s;
-		const size_t n = e - s;
-		bline.push_back({ s, n });
-		// split(/\t\t|\t/): fields 0, 1, 2 in place (a trailing empty field does not exist)
-		Span f[3] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
-		int nf = 0;
-		size_t a = 0, i = 0;
-		while (i < n && nf < 3) {
-			if (ln[i] == '\t') {
-				f[nf++] = { a, i - a };
-				i += (i + 1 < n && ln[i + 1] == '\t') ? 2 : 1;
-				a = i;
-			} else {
-				i++;
+	line_simid.reserve(n_lines);
+	for (auto &v : part) {
+		for (const LineInfo &li : v) {
+			bline.push_back({ li.s, li.n });
+			bid.push_back({ li.s, li.id_n });
+			const char *simp = bt.data() + li.s + li.sim_s, *linp = bt.data() + li.s + li.lin_s;
+			uint32_t sid = 0xFFFFFFFFu;
+			for (auto r = sim_memo.equal_range(li.sim_h); r.first != r.second; ++r.first)
+				if (r.first->second.n == li.sim_n && memcmp(bt.data() + r.first->second.s, simp, li.sim_n) == 0) {
+					sid = r.first->second.id;
+					break;
+				}
+			if (sid == 0xFFFFFFFFu) {
+				sid = (uint32_t)sim_text.size();
+				sim_text.emplace_back(simp, li.sim_n);
+				sim_memo.emplace(li.sim_h, SimMemo{ li.s + li.sim_s, li.sim_n, sid });
 			}
+			line_simid.push_back(sid);
+			const Memo *m = nullptr;
+			for (auto r = lin_memo.equal_range(li.lin_h); r.first != r.second; ++r.first)
+				if (r.first->second.n == li.lin_n && memcmp(bt.data() + r.first->second.s, linp, li.lin_n) == 0) {
+					m = &r.first->second;
+					break;
+				}
+			if (!m) {
+				lineage_tokens(std::string(linp, li.lin_n), tk);
+				const uint32_t t0 = (uint32_t)lin_tok.size();
+				for (auto &t : tk)
+					lin_tok.push_back(intern_into(tmap, ttext, t));
+				m = &lin_memo.emplace(li.lin_h, Memo{ li.s + li.lin_s, li.lin_n, t0, (uint32_t)tk.size() })->second;
+			}
+			tok.insert(tok.end(), lin_tok.begin() + m->first, lin_tok.begin() + m->first + m->count);
+			tok_off.push_back((uint32_t)tok.size());
 		}
-		if (nf < 3 && n > 0 && a < n)
-			f[nf++] = { a, n - a };
-		bid.push_back({ s + f[0].s, f[0].n });
-		key.assign(ln + f[2].s, f[2].n);
-		auto si = sim_id.find(key);
-		if (si == sim_id.end()) {
-			si = sim_id.emplace(key, (uint32_t)sim_text.size()).first;
-			sim_text.push_back(key);
-		}
-		line_simid.push_back(si->second);
-		key.assign(ln + f[1].s, f[1].n);
-		auto li = lin_memo.find(key);
-		if (li == lin_memo.end()) {
-			lineage_tokens(key, tk);
-			const uint32_t t0 = (uint32_t)lin_tok.size();
-			for (auto &t : tk)
-				lin_tok.push_back(intern_into(tmap, ttext, t));
-			li = lin_memo.emplace(key, std::make_pair(t0, (uint32_t)tk.size())).first;
-		}
-		for (uint32_t k = 0; k < li->second.second; k++)
-			tok.push_back(lin_tok[li->second.first + k]);
-		tok_off.push_back((uint32_t)tok.size());
-		s = e + 1;
+		std::vector<LineInfo>().swap(v);
 	}
 	std::map<std::string, uint32_t> simrank;
 	build_sim_ranks(sim_text, simrank);
@@ -967,6 +1053,7 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 		return bid[line].n == x.size() && memcmp(bt.data() + bid[line].s, x.data(), x.size()) == 0;
 	};
 
+	const auto t2 = t_now();
 	// ---- RDP lines (Consensus:126-132) and the cursor walk over both files (Consensus:96-240)
 	std::vector<uint32_t> rdp_off(1, 0), rdp_name;
 	std::vector<int8_t> rdp_rank;
@@ -1046,6 +1133,7 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 		rdp_index++;
 	}
 
+	const auto t3 = t_now();
 	// ---- device: agreement counts + arg-max per group
 	const size_t ng = g_first.size();
 	std::vector<pgx_consensus_rec> recs(ng);
@@ -1096,11 +1184,15 @@ int pgx_consensus_file(const char *b, const char *r, const char *s_or_null, cons
 		snprintf(tmp, sizeof tmp, "#Matches found: %d\n", recs[g].matches);
 		out += tmp;
 	}
+	const auto t4 = t_now();
 	int wrc = write_text_file(o, out);
 	if (wrc < 0) {
 		log.printf("Error: Unable to open output file %s.\n", o);
 		return done(wrc);
 	}
+	if (trace)
+		fprintf(stderr, "[pgx trace] consensus verb: files %.0f ms, hit table %.0f ms, RDP + cursor walk %.0f ms, device + text %.0f ms, write %.0f ms\n",
+			t_ms(t0, t1), t_ms(t1, t2), t_ms(t2, t3), t_ms(t3, t4), t_ms(t4, t_now()));
 	if (status == 0)
 		log.s += "\nDone!\n"; // Consensus:242
 	return done(status);
