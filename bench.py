@@ -102,10 +102,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    # test aid for a one-GPU box: PGX_BENCH_ONE_DEVICE=1 puts every rank on device 0 and PGX_BENCH_BACKEND=gloo replaces
+    # RCCL (which refuses two ranks on one device), so that the N > 1 code path can be exercised end to end
+    if os.environ.get("PGX_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("PGX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda:%d" % local_rank)  # torch's HIP context first (RCCL needs it)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     import pangea_plus_amd as pg
     from pangea_plus_amd import _capi
     pg.init(local_rank)
@@ -187,6 +195,8 @@ def main():
             if os.path.exists(tp):
                 try:
                     traffic = json.load(open(tp)).get("k_seed_extend_bytes_per_launch")
+                    if not (B == 10_000_000 and args.n_seq == pg.SynthCfg.default().n_seq):
+                        traffic = None  # the counter figure is for the default launch only
                 except Exception:
                     traffic = None
             out = {
