@@ -119,6 +119,14 @@ double o_perl_num(const char *s, size_t n);
 int o_megaclust2(const o_megaclust_opts *o, obuf *log);
 int o_megaclust2_main(int argc, char **argv, obuf *log);    /* argv[0] is the program name */
 int o_megaclustable_main(int argc, char **argv, obuf *log);
+
+/* ---------- Trim/trim2.4.pl, FASTQ and QSEQ inputs (o_trim.c) ---------- */
+typedef struct {
+	const char *a, *b, *g, *t, *q; /* raw option texts, NULL = not given (getopts 'a:b:g:t:q:qc:lc:j') */
+	int j;
+} o_trim_opts;
+int o_trim2(const o_trim_opts *o, obuf *out, obuf *fasta, int *fasta_made, int *qseq);
+int o_trim2_main(int argc, char **argv, obuf *out); /* argv[0] is the program name; writes the script's files */
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
  *   pgx_oracle consensus -b blast_class.tsv -r rdp.tsv [-s soap] -o out.txt
  *   pgx_oracle megaclust2 -i consensus.txt -o table.csv [-s -e -b -d -c -h]   (Megaclust/megaclust2.pl)
  *   pgx_oracle megaclustable -m a.csv b.csv ... -t LEVEL -o table.txt          (Megaclustable/megaclustable.pl)
+ *   pgx_oracle trim2 -a reads [-b mates] [-g GAP] [-t TRUNCATE]                 (Trim/trim2.4.pl, FASTQ / QSEQ input)
  */
 #include "o_common.h"
 #include "o_classify.h"
@@ -75,6 +76,16 @@ int main(int argc, char **argv)
 		int rc = verb[9] == '2' ? o_megaclust2_main(argc - 1, argv + 1, &log) : o_megaclustable_main(argc - 1, argv + 1, &log);
 		fwrite(log.p ? log.p : "", 1, log.n, stdout);
 		obuf_free(&log);
+		return rc < 0 ? 2 : 0;
+	}
+	if (strcmp(verb, "trim2") == 0) {
+		obuf out;
+		obuf_init(&out);
+		int rc = o_trim2_main(argc - 1, argv + 1, &out);
+		fwrite(out.p ? out.p : "", 1, out.n, stdout);
+		obuf_free(&out);
+		if (rc == -1)
+			fprintf(stderr, "pgx_oracle trim2: input or option not covered by the restatement (FASTA-format input, negative -t)\n");
 		return rc < 0 ? 2 : 0;
 	}
 	if (strcmp(verb, "tax_class") == 0) {
