@@ -258,6 +258,25 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
  * script's @ARGV (no program name).  Byte-identical output file; `log_text` = its stdout. */
 int pgx_megaclustable(int argc, const char *const *argv, char **log_text);
 
+/* --- the step before the path: Trim/trim2.4.pl == trim2.3.pl on FASTQ and QSEQ reads ---------
+ * `perl trim2.3.pl -a reads_1 [-b reads_2] [-g GAP] [-t TRUNCATE]` (README.md:34; trim2.4.pl:46-167): the raw
+ * getopts values (NULL = option not given; `-qc`, `-lc`, `-q`, `-j` have no effect on these formats, trim2.4.pl:51).
+ * Line index, the running-sum quality rule (trim2.4.pl:529-578 FASTQ, :253-298 QSEQ), mate joining with GAP N's
+ * (:228-245, :502-505) and the FASTA text are computed on the device.
+ *   fasta_text  what the script writes to output_files/trim2/<basename of -a>_runblast.fasta (:115); NULL when the
+ *               script exits before opening it (usage, unopenable file)
+ *   log_text    the script's messages; its stdout is fasta_text followed by log_text in FASTQ mode (:487-515 print
+ *               every record to both), log_text alone otherwise
+ *   mode        PGX_TRIM_*; for PGX_TRIM_QSEQ the script also creates <dirname of -a>/singletons/<basename>_single.txt,
+ *               empty (:176-178)
+ * FASTA-format input (parse_fasta / join_fasta, :301-465) returns PGX_E_FORMAT, a negative -t PGX_E_ARG. */
+typedef struct {
+	const char *a, *b, *g, *t, *q;
+	int j;
+} pgx_trim_opts;
+enum { PGX_TRIM_NONE = 0, PGX_TRIM_FASTQ = 1, PGX_TRIM_QSEQ = 2, PGX_TRIM_UNKNOWN = 3 };
+int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fasta_text, size_t *fasta_len, int *mode);
+
 /* instrumentation for bench.py: HIP-event time (ms) of the kernels of the last pipeline call */
 typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;

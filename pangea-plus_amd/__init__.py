@@ -8,5 +8,5 @@ HIP library is missing or no GPU is visible, every compute call raises PangeaErr
 from ._capi import (  # noqa: F401
     PangeaError, lib, lib_path, init, device_count, version,
     SynthCfg, Db, Reads, Hits, Rdp, TaxDb, StageTimes,
-    blastn, soap, soap_index, makeblastdb, tax_class, taxcollector, consensus, megaclust2, megaclustable, megaclust_batch,
+    blastn, soap, soap_index, makeblastdb, tax_class, taxcollector, consensus, megaclust2, megaclustable, megaclust_batch, trim2,
 )

@@ -93,7 +93,7 @@ SYMBOLS = [
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus",
-    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable",
+    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file",
 ]
 
 
@@ -127,6 +127,7 @@ def _declare(L):
     sig("pgx_megaclust_file", C.c_int, [V, V])
     sig("pgx_megaclust_batch", C.c_int, [V, V, V, V, I64, V, V, V, V])
     sig("pgx_megaclustable", C.c_int, [C.c_int, V, V])
+    sig("pgx_trim_file", C.c_int, [V, V, V, V, V])
     sig("pgx_free", None, [V])
     for name in ("pgx_db_close", "pgx_reads_close", "pgx_hits_close", "pgx_rdp_close", "pgx_tax_close"):
         sig(name, None, [V])
@@ -470,6 +471,28 @@ def megaclustable(argv):
     text = _take_text(log.value)
     _check(rc)
     return text
+
+
+class _TrimOpts(C.Structure):
+    _fields_ = [("a", C.c_char_p), ("b", C.c_char_p), ("g", C.c_char_p), ("t", C.c_char_p), ("q", C.c_char_p), ("j", C.c_int)]
+
+
+TRIM_NONE, TRIM_FASTQ, TRIM_QSEQ, TRIM_UNKNOWN = 0, 1, 2, 3
+
+
+def trim2(a, b=None, g=None, t=None, q=None, j=False):
+    """`perl Trim/trim2.3.pl -a READS_1 [-b READS_2] [-g GAP] [-t TRUNCATE]` (reference README.md:34) on FASTQ or QSEQ
+    input.  Returns (stdout bytes, runblast FASTA bytes or None, mode): the script writes the FASTA to
+    output_files/trim2/<basename of a>_runblast.fasta; writing it is left to the caller (bin/trim2 does it)."""
+    txt = lambda v: None if v is None else str(v).encode()  # noqa: E731  option texts, as on the command line
+    opts = _TrimOpts(_b(a), _b(b), txt(g), txt(t), txt(q), 1 if j else 0)
+    log, fasta, ln, mode = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
+    rc = lib().pgx_trim_file(C.byref(opts), C.byref(log), C.byref(fasta), C.byref(ln), C.byref(mode))
+    messages = _take_text(log.value)
+    made = bool(fasta.value)
+    text = _take_text(fasta.value, ln.value) if made else None
+    _check(rc)
+    return (text + messages if mode.value == TRIM_FASTQ else messages), text, mode.value
 
 
 def consensus(b, r, o, s=None):

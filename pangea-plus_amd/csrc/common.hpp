@@ -116,4 +116,8 @@ int write_text_file(const char *path, const std::string &s);
 
 void trace_point(const char *what);
 
+// Perl semantics shared by the script drop-ins (megaclust.hip): numification of a string, truth of an option value
+double perl_num(const char *s, size_t n);
+bool perl_true(const char *v);
+
 } // namespace pgx

@@ -27,7 +27,7 @@ static inline bool p_space(char c) { return c == ' ' || c == '\t' || c == '\n' |
 
 // what `<`, `>` and `+=` make of a string (perlnumber): optional blanks and sign, Inf/NaN, decimal digits
 // with optional fraction and exponent; anything else counts as 0, trailing text is ignored
-static double perl_num(const char *s, size_t n)
+double perl_num(const char *s, size_t n)
 {
 	size_t i = 0;
 	while (i < n && p_space(s[i]))
@@ -66,7 +66,7 @@ static double perl_num(const char *s, size_t n)
 static double perl_num(const std::string &s) { return perl_num(s.data(), s.size()); }
 
 // Perl truth of an option value: undef, "" and "0" are false
-static bool perl_true(const char *v) { return v && v[0] && !(v[0] == '0' && v[1] == 0); }
+bool perl_true(const char *v) { return v && v[0] && !(v[0] == '0' && v[1] == 0); }
 
 struct Field {
 	const char *p;
