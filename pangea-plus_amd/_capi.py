@@ -482,8 +482,9 @@ TRIM_NONE, TRIM_FASTQ, TRIM_QSEQ, TRIM_UNKNOWN = 0, 1, 2, 3
 
 def trim2(a, b=None, g=None, t=None, q=None, j=False):
     """`perl Trim/trim2.3.pl -a READS_1 [-b READS_2] [-g GAP] [-t TRUNCATE]` (reference README.md:34) on FASTQ or QSEQ
-    input.  Returns (stdout bytes, runblast FASTA bytes or None, mode): the script writes the FASTA to
-    output_files/trim2/<basename of a>_runblast.fasta; writing it is left to the caller (bin/trim2 does it)."""
+    input.  Returns (messages, runblast FASTA bytes or None, mode): the script writes the FASTA to
+    output_files/trim2/<basename of a>_runblast.fasta, which is left to the caller (bin/trim2 does it); its stdout is
+    the FASTA followed by the messages when mode == TRIM_FASTQ, the messages alone otherwise."""
     txt = lambda v: None if v is None else str(v).encode()  # noqa: E731  option texts, as on the command line
     opts = _TrimOpts(_b(a), _b(b), txt(g), txt(t), txt(q), 1 if j else 0)
     log, fasta, ln, mode = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_int()
@@ -492,7 +493,7 @@ def trim2(a, b=None, g=None, t=None, q=None, j=False):
     made = bool(fasta.value)
     text = _take_text(fasta.value, ln.value) if made else None
     _check(rc)
-    return (text + messages if mode.value == TRIM_FASTQ else messages), text, mode.value
+    return messages, text, mode.value
 
 
 def consensus(b, r, o, s=None):

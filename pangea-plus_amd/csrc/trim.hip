@@ -14,6 +14,8 @@
 // Not covered: FASTA-format input (parse_fasta / join_fasta, trim2.4.pl:301-465) and a negative -t.
 #include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -140,20 +142,38 @@ __device__ __forceinline__ Span line_of(const TextView &t, uint64_t i)
 
 __device__ __forceinline__ bool p_space_dev(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 
+// f(byte, index) for the bytes [off, off + n) of the text, in order, read as aligned 16-byte words: one lane per
+// record walking single bytes would pull every 64-byte line from L2 once per byte (the lanes of a wavefront are a
+// record apart, so nothing is shared in L1).  The text buffer is 16-byte aligned with 16 bytes of padding.
+template <typename F> __device__ __forceinline__ void for_bytes(const uint8_t *__restrict__ text, uint64_t off, uint64_t n, F f)
+{
+	const uint64_t hi = off + n;
+	for (uint64_t w = off & ~15ull; w < hi; w += 16) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(text + w);
+		const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint64_t i = w + j;
+			if (i >= off && i < hi)
+				f((uint8_t)(q[j >> 2] >> (8 * (j & 3))), i - off);
+		}
+	}
+}
+
 // trim2.4.pl:535-563 / :264-287: first index at which the clamped running sum reaches its overall maximum
-__device__ uint64_t quality_end(const uint8_t *__restrict__ q, uint64_t n, int offset)
+__device__ uint64_t quality_end(const uint8_t *__restrict__ text, uint64_t off, uint64_t n, int offset)
 {
 	long long max = 0, sum = 0;
 	uint64_t end = 0;
-	for (uint64_t a = 0; a < n; a++) {
-		sum += (long long)q[a] - offset - kQualityCutoff;
+	for_bytes(text, off, n, [&](uint8_t c, uint64_t a) {
+		sum += (long long)c - offset - kQualityCutoff;
 		if (sum > max) {
 			max = sum;
 			end = a;
 		}
 		if (sum < 0)
 			sum = 0;
-	}
+	});
 	return end;
 }
 
@@ -215,20 +235,19 @@ __global__ __launch_bounds__(256) void k_fq_measure(TextView t, uint64_t n_rec, 
 	if (hdr.n && t.text[hdr.off + hdr.n - 1] == '\n')
 		hdr.n--; // chomp($header1)
 	uint64_t len = 1 + 4 + 1; // '>' ":AB\n" "\n"
-	for (uint64_t i = 0; i < hdr.n; i++)
-		len += t.text[hdr.off + i] != '@'; // s/@//g
+	for_bytes(t.text, hdr.off, hdr.n, [&](uint8_t c, uint64_t) { len += c != '@'; }); // s/@//g
 	FqRec f = { kZeroRead, kZeroRead };
 	bool bad = false;
 	for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
 		const Span seq = line_of(t, l0 + 4 * mate + 1), qual = line_of(t, l0 + 4 * mate + 3);
 		bad |= seq.n >= 0x7FFFFFFFull;
-		const uint64_t end = quality_end(t.text + qual.off, qual.n, 33);
+		const uint64_t end = quality_end(t.text, qual.off, qual.n, 33);
 		const uint64_t kept = end < seq.n ? end : seq.n;
 		if (kept >= kLengthCutoff && !bad) {
 			if (mate == 0) {
 				f.keep1 = (uint32_t)kept;
-				for (uint64_t i = 0; i < kept; i++)
-					len += !p_space_dev(t.text[seq.off + i]); // $fastq1 =~ s/\s//g (also the tab of :571)
+				// $fastq1 =~ s/\s//g (also the tab of :571)
+				for_bytes(t.text, seq.off, kept, [&](uint8_t c, uint64_t) { len += !p_space_dev(c); });
 			} else {
 				f.keep2 = (uint32_t)kept;
 				len += kept + 1; // the second mate keeps its tab (:571, :508)
@@ -248,16 +267,15 @@ __global__ __launch_bounds__(256) void k_fq_measure(TextView t, uint64_t n_rec, 
 __global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int paired, uint64_t gap, const FqRec *__restrict__ rec,
 						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
 {
-	const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-	if (r >= n_rec)
-		return;
+	auto same = [](uint8_t c) { return c; };
+	// a bounded grid of wavefronts strides over the records (one wavefront per record costs more in launches than in work)
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += (uint64_t)gridDim.x * (blockDim.x / 64)) {
 	const uint64_t l0 = r * (paired ? 8 : 4);
 	uint64_t pos = out_off[r];
 	Span hdr = line_of(t, l0);
 	if (hdr.n && t.text[hdr.off + hdr.n - 1] == '\n')
 		hdr.n--;
 	const FqRec f = rec[r];
-	auto same = [](uint8_t c) { return c; };
 	w_lit(out, pos, ">", 1);
 	w_copy(out, pos, t.text + hdr.off, hdr.n, [](uint8_t c) { return c != '@'; }, same);
 	w_lit(out, pos, ":AB\n", 4);
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int
 		}
 	}
 	w_lit(out, pos, "\n", 1);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------- QSEQ
@@ -299,22 +318,26 @@ __device__ QsFields qs_split(const uint8_t *__restrict__ text, Span line)
 	uint64_t st = 0;
 	int k = 0;
 	bool have_hdr = false;
-	for (uint64_t i = 0; i <= line.n && k <= 9; i++) {
-		if (i == line.n || text[line.off + i] == '\t') {
-			const Span f = { line.off + st, i - st };
-			if (k == 7) {
-				q.f7 = f;
-				q.hdr_len = (uint32_t)i;
-				have_hdr = true;
-			} else if (k == 8) {
-				q.f8 = f;
-			} else if (k == 9) {
-				q.f9 = f;
-			}
-			k++;
-			st = i + 1;
+	auto close_field = [&](uint64_t i) {
+		const Span f = { line.off + st, i - st };
+		if (k == 7) {
+			q.f7 = f;
+			q.hdr_len = (uint32_t)i;
+			have_hdr = true;
+		} else if (k == 8) {
+			q.f8 = f;
+		} else if (k == 9) {
+			q.f9 = f;
 		}
-	}
+		k++;
+		st = i + 1;
+	};
+	for_bytes(text, line.off, line.n, [&](uint8_t c, uint64_t i) {
+		if (c == '\t' && k <= 9)
+			close_field(i);
+	});
+	if (k <= 9)
+		close_field(line.n); // the last field ends with the line
 	if (!have_hdr) { // fewer than 8 fields: the whole line, then one ':' per missing field
 		q.hdr_len = (uint32_t)line.n;
 		q.pad = (uint32_t)(8 - k);
@@ -338,7 +361,7 @@ __device__ bool qs_trim(const uint8_t *__restrict__ text, Span seq, Span qual, l
 		drop = (uint64_t)(-t2) < seq.n ? seq.n - (uint64_t)(-t2) : 0;
 	seq.off += drop;
 	seq.n -= drop;
-	const uint64_t end = quality_end(text + qual.off, qual.n, 64);
+	const uint64_t end = quality_end(text, qual.off, qual.n, 64);
 	kept->off = seq.off;
 	kept->n = end < seq.n ? end : seq.n;
 	return kept->n >= kLengthCutoff;
@@ -384,12 +407,10 @@ __global__ __launch_bounds__(256) void k_qs_measure(TextView a, TextView b, uint
 __global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_t n_rec, uint64_t gap, const QsRec *__restrict__ rec,
 						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
 {
-	const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-	if (r >= n_rec)
-		return;
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += (uint64_t)gridDim.x * (blockDim.x / 64)) {
 	uint64_t pos = out_off[r];
 	if (out_off[r + 1] == pos)
-		return; // a mate did not survive: nothing is written for the pair (:199-210)
+		continue; // a mate did not survive: nothing is written for the pair (:199-210)
 	const QsRec q = rec[r];
 	const bool dots = (q.pad_dots & 16u) != 0;
 	auto all = [](uint8_t) { return true; };
@@ -402,6 +423,7 @@ __global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_
 	w_fill(out, pos, 'N', gap);
 	w_copy(out, pos, b.text + q.s2, q.n2, all, base);
 	w_lit(out, pos, "\n", 1);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -422,12 +444,29 @@ template <typename In, typename Out> static int exclusive_sum(const In *in, Out 
 	return 0;
 }
 
+// PGX_TRIM_TIMES=1: wall time of each stage to stderr (synchronising; tools/probe_trim.py reads it)
+struct StageClock {
+	bool on = getenv("PGX_TRIM_TIMES") != nullptr;
+	std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+	void tick(const char *what)
+	{
+		if (!on)
+			return;
+		(void)hipDeviceSynchronize();
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[pgx trim] %-10s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+		last = now;
+	}
+};
+static StageClock g_clock;
+
 // the text into HBM and its line index
 static int upload_lines(const std::string &s, DeviceText &d)
 {
 	d.n = s.size();
 	PGX_TRY(d.text.alloc(d.n, 0, 16));
 	PGX_TRY(d.text.upload((const uint8_t *)s.data(), d.n));
+	g_clock.tick("upload");
 	const uint64_t n_tiles = (d.n + kNlTile - 1) / kNlTile;
 	if (n_tiles >= 0x7FFFFFFFull)
 		return fail(PGX_E_LIMIT, "read file of %llu bytes is beyond the line indexer's range", (unsigned long long)d.n);
@@ -452,8 +491,13 @@ static int upload_lines(const std::string &s, DeviceText &d)
 	if (open_tail)
 		PGX_HIP(hipMemcpy(d.start.data() + d.n_lines, &d.n, sizeof d.n, hipMemcpyHostToDevice));
 	trace_point("trim line index");
+	g_clock.tick("line index");
 	return 0;
 }
+
+// blocks of four wavefronts for the record writers: enough to fill 256 CUs several times over, few enough that a
+// wavefront writes many records
+static unsigned emit_grid(uint64_t n_rec) { return (unsigned)std::min<uint64_t>((n_rec + 3) / 4, 256u * 32u); }
 
 static int take_output(const DevBuf<char> &out, uint64_t total, char **text, size_t *len)
 {
@@ -491,17 +535,21 @@ static int trim_fastq_device(const std::string &a, bool paired, uint64_t gap, ch
 	uint32_t bad = 0;
 	PGX_TRY(out_off.download(&total, 1, n_rec));
 	PGX_TRY(flag.download(&bad, 1));
+	g_clock.tick("measure");
 	if (bad)
 		return fail(PGX_E_LIMIT, "a FASTQ line of 2 GiB or more");
 	DevBuf<char> out;
 	PGX_TRY(out.alloc(total));
 	if (n_rec) {
-		hipLaunchKernelGGL(k_fq_emit, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, 0, da.view(), n_rec, paired ? 1 : 0, gap, rec.data(),
+		hipLaunchKernelGGL(k_fq_emit, dim3(emit_grid(n_rec)), dim3(256), 0, 0, da.view(), n_rec, paired ? 1 : 0, gap, rec.data(),
 				   out_off.data(), out.data());
 		PGX_HIP(hipGetLastError());
 	}
 	trace_point("trim fastq");
-	return take_output(out, total, text, len);
+	g_clock.tick("emit");
+	const int rc = take_output(out, total, text, len);
+	g_clock.tick("download");
+	return rc;
 }
 
 static int trim_qseq_device(const std::string &a, const std::string &b, uint64_t gap, long long t1, long long t2, char **text, size_t *len)
@@ -528,17 +576,21 @@ static int trim_qseq_device(const std::string &a, const std::string &b, uint64_t
 	uint32_t bad = 0;
 	PGX_TRY(out_off.download(&total, 1, n_rec));
 	PGX_TRY(flag.download(&bad, 1));
+	g_clock.tick("measure");
 	if (bad)
 		return fail(PGX_E_LIMIT, "a QSEQ line of 2 GiB or more");
 	DevBuf<char> out;
 	PGX_TRY(out.alloc(total));
 	if (n_rec) {
-		hipLaunchKernelGGL(k_qs_emit, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, 0, da.view(), db.view(), n_rec, gap, rec.data(),
+		hipLaunchKernelGGL(k_qs_emit, dim3(emit_grid(n_rec)), dim3(256), 0, 0, da.view(), db.view(), n_rec, gap, rec.data(),
 				   out_off.data(), out.data());
 		PGX_HIP(hipGetLastError());
 	}
 	trace_point("trim qseq");
-	return take_output(out, total, text, len);
+	g_clock.tick("emit");
+	const int rc = take_output(out, total, text, len);
+	g_clock.tick("download");
+	return rc;
 }
 
 static const char *const kTrimUsage = // trim2.4.pl:54-63
@@ -592,6 +644,7 @@ extern "C" int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fas
 		return finish(0);
 	}
 	bool ok = false;
+	g_clock.tick("start");
 	const std::string a = read_text_file(o->a, &ok);
 	if (!ok) {
 		log.printf("Error: Unable to open %s.\n", o->a); // :68-71
@@ -622,6 +675,7 @@ extern "C" int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fas
 	if (!a.empty() && a[0] == '>')
 		return finish(fail(PGX_E_FORMAT, "%s is FASTA: only FASTQ and QSEQ input is covered (trim2.4.pl parse_fasta / join_fasta are not)", o->a));
 	int rc = 0;
+	g_clock.tick("read files");
 	if (!a.empty() && a[0] == '@') { // :146-149
 		*mode = PGX_TRIM_FASTQ;
 		rc = trim_fastq_device(a, paired, gap, fasta_text, fasta_len);
