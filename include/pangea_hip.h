@@ -258,6 +258,12 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
  * script's @ARGV (no program name).  Byte-identical output file; `log_text` = its stdout. */
 int pgx_megaclustable(int argc, const char *const *argv, char **log_text);
 
+/* Columns 11-12 (e-value, bit score) of a `blastn -outfmt 6` row (README.md:96) for a raw score, as the row formatter
+ * prints them: lambda 1.28, K 0.46 (reward 1 / penalty -2), BLAST+ tabular number formats.  Host arithmetic only.
+ * The reference's only record of its BLAST dependency's output, validation_dataset/Data-set_2_consensus.xlsx
+ * (10 992 rows), is the known-answer set for it (tests/golden/blast_rows). */
+int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, char evalue[32], char bits[32]);
+
 /* --- the step before the path: Trim/trim2.4.pl == trim2.3.pl on FASTQ and QSEQ reads ---------
  * `perl trim2.3.pl -a reads_1 [-b reads_2] [-g GAP] [-t TRUNCATE]` (README.md:34; trim2.4.pl:46-167): the raw
  * getopts values (NULL = option not given; `-qc`, `-lc`, `-q`, `-j` have no effect on these formats, trim2.4.pl:51).

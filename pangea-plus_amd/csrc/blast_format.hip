@@ -140,6 +140,24 @@ void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_ns
 	bits = bs;
 }
 
+} // namespace pgx
+
+// columns 11-12 of an `-outfmt 6` row as the row formatter prints them (pure arithmetic on the host: the table the
+// device formatter indexes is filled by this function); exported so that the known BLAST+ rows of the reference's
+// validation spreadsheet can be checked against the product itself (tests/test_gpu_blast_rows.py)
+extern "C" int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, char evalue[32], char bits[32])
+{
+	if (!evalue || !bits || qlen <= 0 || db_len <= 0 || db_nseq <= 0)
+		return pgx::fail(PGX_E_ARG, "pgx_blast_score_columns: bad argument");
+	std::string e, b;
+	pgx::format_score_columns(score, qlen, db_len, db_nseq, e, b);
+	snprintf(evalue, 32, "%s", e.c_str());
+	snprintf(bits, 32, "%s", b.c_str());
+	return 0;
+}
+
+namespace pgx {
+
 // host rendering, one snprintf per column: kept for batches whose (read length x score) table would be huge
 static int format_hits_text_host(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)
 {
