@@ -264,18 +264,14 @@ __global__ __launch_bounds__(256) void k_fq_measure(TextView t, uint64_t n_rec, 
 	out_len[r] = len;
 }
 
-__global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int paired, uint64_t gap, const FqRec *__restrict__ rec,
-						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
+// the FASTA text of record `r`, written by one wavefront (trim2.4.pl:487-515)
+__device__ void fq_emit_record(const TextView &t, uint64_t r, int paired, uint64_t gap, const FqRec f, uint64_t pos, char *__restrict__ out)
 {
-	auto same = [](uint8_t c) { return c; };
-	// a bounded grid of wavefronts strides over the records (one wavefront per record costs more in launches than in work)
-	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += (uint64_t)gridDim.x * (blockDim.x / 64)) {
 	const uint64_t l0 = r * (paired ? 8 : 4);
-	uint64_t pos = out_off[r];
 	Span hdr = line_of(t, l0);
 	if (hdr.n && t.text[hdr.off + hdr.n - 1] == '\n')
 		hdr.n--;
-	const FqRec f = rec[r];
+	auto same = [](uint8_t c) { return c; };
 	w_lit(out, pos, ">", 1);
 	w_copy(out, pos, t.text + hdr.off, hdr.n, [](uint8_t c) { return c != '@'; }, same);
 	w_lit(out, pos, ":AB\n", 4);
@@ -293,7 +289,15 @@ __global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int
 		}
 	}
 	w_lit(out, pos, "\n", 1);
-	}
+}
+
+// a bounded grid of wavefronts strides over the records
+__global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int paired, uint64_t gap, const FqRec *__restrict__ rec,
+						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
+{
+	const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x / 64);
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += waves)
+		fq_emit_record(t, r, paired, gap, rec[r], out_off[r], out);
 }
 
 // ------------------------------------------------------------------------------------------------- QSEQ
@@ -404,14 +408,9 @@ __global__ __launch_bounds__(256) void k_qs_measure(TextView a, TextView b, uint
 	out_len[r] = len;
 }
 
-__global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_t n_rec, uint64_t gap, const QsRec *__restrict__ rec,
-						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
+// the FASTA text of pair `r`, written by one wavefront (trim2.4.pl:218-245)
+__device__ void qs_emit_record(const TextView &a, const TextView &b, uint64_t r, uint64_t gap, const QsRec q, uint64_t pos, char *__restrict__ out)
 {
-	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += (uint64_t)gridDim.x * (blockDim.x / 64)) {
-	uint64_t pos = out_off[r];
-	if (out_off[r + 1] == pos)
-		continue; // a mate did not survive: nothing is written for the pair (:199-210)
-	const QsRec q = rec[r];
 	const bool dots = (q.pad_dots & 16u) != 0;
 	auto all = [](uint8_t) { return true; };
 	auto base = [dots](uint8_t c) { return dots && c == '.' ? (uint8_t)'N' : c; };
@@ -423,7 +422,15 @@ __global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_
 	w_fill(out, pos, 'N', gap);
 	w_copy(out, pos, b.text + q.s2, q.n2, all, base);
 	w_lit(out, pos, "\n", 1);
-	}
+}
+
+__global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_t n_rec, uint64_t gap, const QsRec *__restrict__ rec,
+						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
+{
+	const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x / 64);
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += waves)
+		if (out_off[r + 1] != out_off[r]) // else a mate did not survive: nothing is written for the pair (:199-210)
+			qs_emit_record(a, b, r, gap, rec[r], out_off[r], out);
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -495,8 +502,7 @@ static int upload_lines(const std::string &s, DeviceText &d)
 	return 0;
 }
 
-// blocks of four wavefronts for the record writers: enough to fill 256 CUs several times over, few enough that a
-// wavefront writes many records
+// blocks of four wavefronts for the record writers: enough to fill 256 CUs several times over
 static unsigned emit_grid(uint64_t n_rec) { return (unsigned)std::min<uint64_t>((n_rec + 3) / 4, 256u * 32u); }
 
 static int take_output(const DevBuf<char> &out, uint64_t total, char **text, size_t *len)

@@ -123,3 +123,56 @@ def test_fasta_input_and_negative_truncate_are_declined(tmp_path):
     (tmp_path / "a.fq").write_bytes(b"@r\nACGT\n+\nIIII\n")
     with pytest.raises(pg.PangeaError, match="negative"):
         pg.trim2(str(tmp_path / "a.fq"), t="-3")
+
+
+def test_trimmed_pairs_through_blastn_equal_the_oracle_chain(oracle_bin, tmp_path):
+    """README.md:34 -> :96 as one chain: QSEQ mates cut from database sequences, trim2 -g 100 (mates joined by 100 N's:
+    the read shape Trim hands to Classify), then blastn.  The product's chain must give the oracle chain's table, and
+    the joined reads must find both mates on their source sequence."""
+    import pangea_plus_amd as pg
+    pg.init(0)
+    rng = random.Random(77)
+    n_seq, n_pairs, L = 400, 1500, 151
+    seqs = ["".join(rng.choice("ACGT") for _ in range(1400)) for _ in range(n_seq)]
+    (tmp_path / "db.fa").write_text("".join(">gi|%d|x|s%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    a, b = [], []
+    for i in range(n_pairs):
+        src = rng.randrange(n_seq)
+        o1 = rng.randrange(0, 500)
+        o2 = o1 + rng.randrange(300, 700)
+        for mate, off, dst in ((1, o1, a), (2, o2, b)):
+            seq = list(seqs[src][off:off + L])
+            for p_ in rng.sample(range(L), rng.choice((0, 0, 1, 3))):
+                seq[p_] = rng.choice("ACGT.")
+            qual = [40] * L if i % 5 else [40] * rng.randint(60, L) + [2] * L
+            dst.append("\t".join(["M", "1", "1", str(src), str(i), "0", "ACGT", str(mate), "".join(seq),
+                                  "".join(chr(64 + q) for q in qual[:L]), "1"]) + "\n")
+    (tmp_path / "a.txt").write_text("".join(a))
+    (tmp_path / "b.txt").write_text("".join(b))
+    argv = ["-a", "a.txt", "-b", "b.txt", "-g", "100"]
+    want_out, want_fasta = oracle_trim(oracle_bin, tmp_path, argv)
+    messages, fasta, mode = pg.trim2(str(tmp_path / "a.txt"), b=str(tmp_path / "b.txt"), g=100)
+    assert fasta == want_fasta and messages == want_out
+    (tmp_path / "reads.fa").write_bytes(fasta)
+    n_reads = fasta.count(b">")
+    assert 1000 < n_reads < n_pairs                      # the pairs with a short high-quality prefix were dropped
+    rc, _, se = run_cmd([oracle_bin, "blastn", "-query", str(tmp_path / "reads.fa"), "-db", str(tmp_path / "db.fa"), "-outfmt", "6",
+                         "-out", str(tmp_path / "want.tsv"), "-num_threads", "8"], timeout=900)
+    assert rc == 0, se
+    pg.makeblastdb(str(tmp_path / "db.fa"), str(tmp_path / "db"))
+    pg.blastn(str(tmp_path / "reads.fa"), str(tmp_path / "db"), str(tmp_path / "got.tsv"))
+    got = (tmp_path / "got.tsv").read_bytes()
+    assert got == (tmp_path / "want.tsv").read_bytes()
+    # both mates of a joined read land on the sequence they were cut from (header field 3 carries its number)
+    rows = {}
+    for line in got.decode().splitlines():
+        f = line.split("\t")
+        rows.setdefault(f[0], []).append(f)
+    both = 0
+    for name, hits in rows.items():
+        src = "gi|%d|x|s%s|" % (int(name.split(":")[3]) + 1, name.split(":")[3])
+        own = [h for h in hits if h[1] == src]
+        left = any(int(h[7]) <= 160 for h in own)
+        right = any(int(h[6]) >= 200 for h in own)
+        both += left and right
+    assert both > 0.9 * n_reads
