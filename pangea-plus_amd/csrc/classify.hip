@@ -1579,10 +1579,51 @@ struct EventTimer {
 };
 
 // Buffers that persist across pipeline calls: the steady state of a batch loop allocates nothing.
+// ------------------------------------------------------------------------------------------ pieces back to reads
+// A batch whose reads hold long N runs was searched piece by piece (seqdb.hip: reads_build_pieces).  Pieces of a read
+// are consecutive, so the exclusive scan of the per-piece counts is already the layout of the per-read table: the
+// hits of every piece are moved there with the read's number and the piece's offset on the query coordinates.
+__global__ __launch_bounds__(256) void k_merge_pieces(const pgx_hit *__restrict__ scratch, const uint32_t *__restrict__ piece_start,
+						      const uint32_t *__restrict__ piece_off, const uint32_t *__restrict__ parent,
+						      const uint32_t *__restrict__ qoff, uint32_t n_pieces, pgx_hit *__restrict__ hits)
+{
+	const uint32_t waves = gridDim.x * (blockDim.x / 64), lane = threadIdx.x & 63;
+	for (uint32_t s = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); s < n_pieces; s += waves) {
+		const uint32_t o = piece_off[s], cnt = piece_off[s + 1] - o;
+		if (cnt == 0)
+			continue;
+		const uint32_t st = piece_start[s];
+		const pgx_hit *src = st == kFragmented ? hits + o : scratch + st; // fragmented pieces were scattered in place
+		const int32_t read = (int32_t)parent[s], shift = (int32_t)qoff[s];
+		for (uint32_t i = lane; i < cnt; i += 64) {
+			pgx_hit h = src[i];
+			h.read = read;
+			h.qstart += shift;
+			h.qend += shift;
+			hits[o + i] = h;
+		}
+	}
+}
+
+__global__ void k_piece_ranges(const uint32_t *__restrict__ piece_first, const uint32_t *__restrict__ piece_off, uint32_t n_reads,
+			       uint32_t *__restrict__ read_off, uint32_t *__restrict__ read_cnt, uint32_t *__restrict__ read_start)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads)
+		return;
+	const uint32_t o = piece_off[piece_first[r]];
+	read_off[r] = o;
+	if (r < n_reads) {
+		read_cnt[r] = piece_off[piece_first[r + 1]] - o;
+		read_start[r] = kFragmented; // the ordering kernels take every read from the grouped table
+	}
+}
+
 struct Workspace {
 	DevBuf<unsigned long long> counters;
 	DevBuf<pgx_hit> scratch, ovf;
 	DevBuf<uint32_t> partial, cursor, big_list, big_count, read_start, mid_list, mid_count;
+	DevBuf<uint32_t> piece_cnt, piece_off, parent_start; // batches searched piece by piece
 	DevBuf<pgx_consensus_rec> recs;
 	pgx_hits hits; // used when the caller does not keep the hit table
 	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0;
@@ -1610,22 +1651,31 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	}
 	index_check(db, "search_pipeline");
 	const DbView dv = db_view(db);
-	const ReadsView rv = reads_view(rd);
+	// the batch the seed stage runs on: the reads, or their pieces (reads with long N runs, engine.hpp)
+	const bool split = rd->pieces && rd->pieces->n > 0; // (no piece at all: every read is N's; search the reads as they are)
+	const pgx_reads *sr = split ? rd->pieces.get() : rd;
+	const uint64_t ns = (uint64_t)sr->n;
+	if (split) {
+		PGX_TRY(g_ws.piece_cnt.ensure(ns + 1));
+		PGX_TRY(g_ws.piece_off.ensure(ns + 1));
+		PGX_TRY(g_ws.parent_start.ensure(n));
+	}
+	const ReadsView rv = reads_view(sr);
 	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
 	EventTimer total, t;
 	total.start();
 
 	// seed + extend: unfragmented reads land contiguously in `scratch`, the rest in `ovf`;
 	// grow and repeat if a guess was too small
-	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(n * 40, 1 << 16) + (uint64_t)grid * kWavesPerBlock * kChunk, g_ws.hit_cap_hint);
-	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(n / 4, 1 << 16), g_ws.ovf_cap_hint);
+	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 40, 1 << 16) + 256ull * 8 * kWavesPerBlock * kChunk, g_ws.hit_cap_hint);
+	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) / 4, 1 << 16), g_ws.ovf_cap_hint);
 	DevBuf<pgx_hit> &scratch = g_ws.scratch, &ovf = g_ws.ovf;
 	DevBuf<uint32_t> &read_start = g_ws.read_start;
-	PGX_TRY(read_start.ensure(n));
+	PGX_TRY(read_start.ensure(std::max(n, ns)));
 	unsigned long long h_cnt[8];
 	// reads are searched class by class (engine.hpp: pgx_reads::classes); a database with ambiguity letters makes every
 	// class ambiguity-aware
-	const std::vector<pgx_reads::SearchClass> &classes = rd->classes;
+	const std::vector<pgx_reads::SearchClass> &classes = sr->classes;
 	bool dense = true; // every read keeps its flags in registers (the ordering kernels then see no read longer than 512)
 	for (auto &c : classes)
 		dense = dense && c.words > 0;
@@ -1648,10 +1698,10 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			ReadsView cvw = rv;
 			const uint64_t cn = c.count;
 			cvw.n = (uint32_t)cn;
-			cvw.list = c.listed ? rd->d_class_list.data() + c.off : nullptr;
+			cvw.list = c.listed ? sr->d_class_list.data() + c.off : nullptr;
 			const int per_block = kWavesPerBlock * (c.words > 0 ? 2 : 1);
 			const dim3 g((unsigned)std::min<uint64_t>((cn + per_block - 1) / per_block, 256ull * 8)), b(64 * kWavesPerBlock);
-			uint32_t *rc_ptr = out->d_read_cnt.data(), *rs_ptr = read_start.data();
+			uint32_t *rc_ptr = split ? g_ws.piece_cnt.data() : out->d_read_cnt.data(), *rs_ptr = read_start.data();
 #define PGX_SEED_LAUNCH(A, W)                                                                                                      \
 	do {                                                                                                                       \
 		if (c.listed)                                                                                                      \
@@ -1704,22 +1754,33 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 
 	// group by read: exclusive scan of the per-read counts; only the overflow hits need a scatter
 	t.start();
-	const uint32_t n_part = (uint32_t)((n + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
+	// (per piece when the batch was searched piece by piece: the scan of the piece counts is the per-read layout too)
+	const uint32_t *unit_cnt = split ? g_ws.piece_cnt.data() : out->d_read_cnt.data();
+	uint32_t *unit_off = split ? g_ws.piece_off.data() : out->d_read_off.data();
+	const uint32_t n_part = (uint32_t)((ns + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
 	DevBuf<uint32_t> &partial = g_ws.partial, &cursor = g_ws.cursor;
 	PGX_TRY(partial.ensure(n_part));
-	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data());
+	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, unit_cnt, ns, partial.data());
 	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, 0, partial.data(), n_part);
-	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, out->d_read_cnt.data(), n, partial.data(),
-			   out->d_read_off.data());
+	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, unit_cnt, ns, partial.data(), unit_off);
 	PGX_HIP(hipGetLastError());
 	PGX_TRY(out->d_hits.ensure(H ? H : 1));
 	if (H_ovf) {
-		PGX_TRY(cursor.ensure(n));
-		PGX_HIP(hipMemsetAsync(cursor.data(), 0, n * sizeof(uint32_t), 0));
+		PGX_TRY(cursor.ensure(ns));
+		PGX_HIP(hipMemsetAsync(cursor.data(), 0, ns * sizeof(uint32_t), 0));
 		const int g2 = (int)std::min<uint64_t>((H_ovf + 255) / 256, 256ull * 16);
-		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, ovf.data(), H_ovf, out->d_read_off.data(),
-				   cursor.data(), out->d_hits.data());
+		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, ovf.data(), H_ovf, unit_off, cursor.data(), out->d_hits.data());
 		PGX_HIP(hipGetLastError());
+	}
+	const uint32_t *sort_start = read_start.data();
+	if (split) {
+		hipLaunchKernelGGL(k_merge_pieces, dim3((unsigned)std::min<uint64_t>((ns + 3) / 4, 256ull * 32)), dim3(256), 0, 0, scratch.data(),
+				   read_start.data(), g_ws.piece_off.data(), rd->d_piece_parent.data(), rd->d_piece_qoff.data(), (uint32_t)ns,
+				   out->d_hits.data());
+		hipLaunchKernelGGL(k_piece_ranges, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, rd->d_piece_first.data(),
+				   g_ws.piece_off.data(), (uint32_t)n, out->d_read_off.data(), out->d_read_cnt.data(), g_ws.parent_start.data());
+		PGX_HIP(hipGetLastError());
+		sort_start = g_ws.parent_start.data();
 	}
 	g_times.group_ms = t.stop();
 	trace_point("group");
@@ -1740,11 +1801,11 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
 	const int grid2 = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
 	hipLaunchKernelGGL(k_sort_consensus<32>, dim3(grid2), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
-			   read_start.data(), out->d_read_off.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv,
+			   sort_start, out->d_read_off.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv,
 			   rdp ? 1 : 0, lds_ok, d_recs, mid_list.data(), mid_count.data());
 	trace_point("k_sort_consensus<32>");
 	hipLaunchKernelGGL(k_sort_consensus<64>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
-			   read_start.data(), out->d_read_off.data(), (uint32_t)n, mid_list.data(), mid_count.data(), cv, rdp ? 1 : 0,
+			   sort_start, out->d_read_off.data(), (uint32_t)n, mid_list.data(), mid_count.data(), cv, rdp ? 1 : 0,
 			   lds_ok, d_recs, big_list.data(), big_count.data());
 	PGX_HIP(hipGetLastError());
 	trace_point("k_sort_consensus<64>");
@@ -1752,7 +1813,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_TRY(big_count.download(&n_big, 1));
 	if (n_big) {
 		// more than 64 hits (or reads too long for the packed keys): segmented radix sorts, any size (bigreads.hip)
-		PGX_TRY(sort_big_reads(out->d_hits.data(), scratch.data(), read_start.data(), out->d_read_off.data(),
+		PGX_TRY(sort_big_reads(out->d_hits.data(), scratch.data(), sort_start, out->d_read_off.data(),
 				       out->d_read_cnt.data(), big_list.data(), n_big));
 		if (rdp) {
 			hipLaunchKernelGGL(k_consensus_serial, dim3((n_big + 63) / 64), dim3(64), 0, 0, out->d_hits.data(),

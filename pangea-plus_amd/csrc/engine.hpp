@@ -88,6 +88,13 @@ struct pgx_reads {
 	int32_t max_len = 0;
 	pgx::DevBuf<uint64_t> d_fwd, d_rc, d_fwd_amb, d_rc_amb;
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
+	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the
+	// stretches between such runs (seqdb.hip: reads_build_pieces): `pieces` is a batch of its own, pieces of a read
+	// are consecutive in it; null when no read of the batch has such a run
+	std::unique_ptr<pgx_reads> pieces;
+	pgx::DevBuf<uint32_t> d_piece_first;  // n+1: first piece of each read
+	pgx::DevBuf<uint32_t> d_piece_parent; // per piece: its read
+	pgx::DevBuf<uint32_t> d_piece_qoff;   // per piece: 0-based offset of its first base in the read
 	std::string name_of(int64_t i) const;
 };
 

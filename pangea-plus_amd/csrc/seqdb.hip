@@ -99,12 +99,13 @@ __global__ void k_pack_db(const unsigned char *__restrict__ letters, uint64_t n,
 // read layout: every read starts on a word boundary; fold_to_g reads every ambiguous letter as G and counts them
 __global__ void k_pack_reads(const unsigned char *__restrict__ letters, const uint64_t *__restrict__ off,
 			     const uint32_t *__restrict__ woff, uint64_t n_reads, int fold_to_g, uint64_t *__restrict__ fwd,
-			     uint64_t *__restrict__ amb, uint32_t *__restrict__ amb_count, unsigned int *__restrict__ any_amb)
+			     uint64_t *__restrict__ amb, uint32_t *__restrict__ amb_count, unsigned int *__restrict__ any_amb,
+			     const uint32_t *__restrict__ len = nullptr)
 {
 	uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads)
 		return;
-	const uint64_t s = off[r], L = off[r + 1] - s;
+	const uint64_t s = off[r], L = len ? (uint64_t)len[r] : off[r + 1] - s; // `len`: ranges that are not back to back (pieces)
 	const uint32_t w0 = woff[r];
 	uint32_t namb = 0;
 	for (uint64_t w = 0; w * 32 < L; w++) {
@@ -997,6 +998,165 @@ static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------ pieces of reads with long N runs
+// Spec S3: an extension stops once the running score is more than X = 10 below its best, and a letter that is not
+// A/C/G/T matches nothing (- 2 per column): no HSP can hold a letter of a run of kSplitRun = 6 or more such letters,
+// and no seed overlaps one.  The stretches between such runs can therefore be searched as reads of their own (most
+// of them free of ambiguity letters: the plain kernels, the small flag classes) and their hits put back per read
+// with the query coordinates shifted (search_pipeline).  This is the shape trim2 -g hands over: two mates joined
+// by 100 or 189 N's (Trim/trim2.4.pl:228-245, :502-505).  Stretches shorter than a seed word hold no hit and are dropped.
+constexpr uint32_t kSplitRun = 6, kMinPiece = 28;
+
+// f(start, length) for every stretch of read letters [s, s + L) kept by the rule above, left to right
+template <typename F> __device__ __forceinline__ void for_pieces(const unsigned char *__restrict__ letters, uint64_t s, uint64_t L, F f)
+{
+	uint64_t st = 0, run = 0; // st: start of the current stretch; run: unknown letters seen just before position i
+	for (uint64_t i = 0; i <= L; i++) {
+		const bool unknown = i < L && letter_code(letters[s + i]) >= 4;
+		if (unknown) {
+			run++;
+			continue;
+		}
+		if (run >= kSplitRun) { // the stretch ended where the run began
+			const uint64_t en = i - run;
+			if (en - st >= kMinPiece)
+				f(st, en - st);
+			st = i;
+		}
+		run = 0;
+		if (i == L && L - st >= kMinPiece && st < L)
+			f(st, L - st);
+	}
+}
+
+// pieces per read; reads with fewer than kSplitRun unknown letters are one piece without a look at their letters
+__global__ void k_piece_count(const unsigned char *__restrict__ letters, const uint64_t *__restrict__ off, const uint32_t *__restrict__ namb,
+			      uint64_t n_reads, uint32_t *__restrict__ n_pieces, unsigned int *__restrict__ any_split)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads)
+		return;
+	if (r == n_reads) {
+		n_pieces[r] = 0;
+		return;
+	}
+	uint32_t c = 1;
+	if (namb[r] >= kSplitRun) {
+		const uint64_t s = off[r], L = off[r + 1] - s;
+		c = 0;
+		bool whole = false;
+		for_pieces(letters, s, L, [&](uint64_t st, uint64_t n) {
+			c++;
+			whole = st == 0 && n == L;
+		});
+		if (!(c == 1 && whole))
+			atomicOr(any_split, 1u);
+	}
+	n_pieces[r] = c;
+}
+
+__global__ void k_piece_fill(const unsigned char *__restrict__ letters, const uint64_t *__restrict__ off, const uint32_t *__restrict__ namb,
+			     uint64_t n_reads, const uint32_t *__restrict__ first, uint64_t *__restrict__ p_start, uint32_t *__restrict__ p_len,
+			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_qoff)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads)
+		return;
+	const uint64_t s = off[r], L = off[r + 1] - s;
+	uint32_t k = first[r];
+	auto put = [&](uint64_t st, uint64_t n) {
+		p_start[k] = s + st;
+		p_len[k] = (uint32_t)n;
+		p_parent[k] = (uint32_t)r;
+		p_qoff[k] = (uint32_t)st;
+		k++;
+	};
+	if (namb[r] >= kSplitRun)
+		for_pieces(letters, s, L, put);
+	else
+		put(0, L);
+}
+
+static int reads_finish(pgx_reads *rd);
+
+// builds rd->pieces (a batch of its own: packed strands, classes) when a read of the batch holds a long N run
+static int reads_build_pieces(pgx_reads *rd, const unsigned char *d_letters, const uint64_t *d_loff, const uint32_t *d_namb)
+{
+	const uint64_t n = (uint64_t)rd->n;
+	if (n == 0 || n >= 0x7FFFFFFFull || rd->max_len >= (1 << 30))
+		return 0;
+	DevBuf<uint32_t> d_pc, d_first;
+	DevBuf<unsigned int> d_flag;
+	PGX_TRY(d_pc.alloc(n + 1));
+	PGX_TRY(d_flag.alloc(1, 0, 0, true));
+	hipLaunchKernelGGL(k_piece_count, dim3((unsigned)((n + 1 + 127) / 128)), dim3(128), 0, 0, d_letters, d_loff, d_namb, n, d_pc.data(),
+			   d_flag.data());
+	PGX_HIP(hipGetLastError());
+	unsigned int any = 0;
+	PGX_TRY(d_flag.download(&any, 1));
+	if (!any)
+		return 0;
+	PGX_TRY(d_first.alloc(n + 1));
+	PGX_TRY(u32_scan(d_pc.data(), d_first.data(), (size_t)n + 1, false));
+	uint32_t np = 0;
+	PGX_TRY(d_first.download(&np, 1, n));
+	std::unique_ptr<pgx_reads> pc(new pgx_reads());
+	pc->n = np;
+	DevBuf<uint64_t> d_pstart;
+	DevBuf<uint32_t> d_plen;
+	PGX_TRY(d_pstart.alloc((size_t)np + 1));
+	PGX_TRY(d_plen.alloc((size_t)np + 1));
+	PGX_TRY(rd->d_piece_parent.alloc((size_t)np + 1));
+	PGX_TRY(rd->d_piece_qoff.alloc((size_t)np + 1));
+	hipLaunchKernelGGL(k_piece_fill, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, d_letters, d_loff, d_namb, n, d_first.data(),
+			   d_pstart.data(), d_plen.data(), rd->d_piece_parent.data(), rd->d_piece_qoff.data());
+	PGX_HIP(hipGetLastError());
+	pc->h_len.resize(np);
+	PGX_TRY(d_plen.download(pc->h_len.data(), np));
+	pc->h_woff.resize((size_t)np + 1);
+	uint64_t nw = 0;
+	for (uint32_t k = 0; k < np; k++) {
+		pc->h_woff[k] = (uint32_t)nw;
+		nw += (pc->h_len[k] + 31) / 32;
+		pc->max_len = std::max<int32_t>(pc->max_len, (int32_t)pc->h_len[k]);
+	}
+	if (nw >= 0xFFFFFFFFull)
+		return 0; // keep the batch unsplit rather than overflow the 32-bit word offsets
+	pc->h_woff[np] = (uint32_t)nw;
+	pc->n_words = (int64_t)nw;
+	DevBuf<uint32_t> d_pnamb;
+	DevBuf<unsigned int> d_pflag;
+	PGX_TRY(pc->d_woff.alloc((size_t)np + 1));
+	PGX_TRY(pc->d_woff.upload(pc->h_woff.data(), (size_t)np + 1));
+	PGX_TRY(pc->d_fwd.alloc((size_t)nw + 24, 0, 0, true));
+	PGX_TRY(pc->d_fwd_amb.alloc((size_t)nw + 24, 0, 0, true));
+	PGX_TRY(d_pnamb.alloc(np ? np : 1));
+	PGX_TRY(d_pflag.alloc(1, 0, 0, true));
+	if (np) {
+		hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, 0, d_letters, d_pstart.data(), pc->d_woff.data(),
+				   (uint64_t)np, 0, pc->d_fwd.data(), pc->d_fwd_amb.data(), d_pnamb.data(), d_pflag.data(), d_plen.data());
+		PGX_HIP(hipGetLastError());
+	}
+	unsigned int pflag = 0;
+	PGX_TRY(d_pflag.download(&pflag, 1));
+	pc->has_amb = pflag != 0;
+	if (!pc->has_amb) {
+		pc->d_fwd_amb.release();
+	} else {
+		std::vector<uint32_t> na(np);
+		PGX_TRY(d_pnamb.download(na.data(), np));
+		pc->h_read_amb.resize(np);
+		for (uint32_t k = 0; k < np; k++)
+			pc->h_read_amb[k] = na[k] != 0;
+	}
+	PGX_TRY(reads_finish(pc.get()));
+	rd->d_piece_first.release();
+	PGX_TRY(rd->d_piece_first.alloc(n + 1));
+	PGX_HIP(hipMemcpy(rd->d_piece_first.data(), d_first.data(), (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+	rd->pieces = std::move(pc);
+	return 0;
+}
+
 int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fold_to_g, std::vector<uint32_t> *amb_count,
 			pgx_reads **out)
 {
@@ -1139,6 +1299,8 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 		rd->h_fwd.assign(nw + 2, 0);
 		rc = rd->d_fwd.download(rd->h_fwd.data(), (size_t)nw);
 	}
+	if (rc == 0 && rd->has_amb && getenv("PGX_NO_PIECES") == nullptr)
+		rc = reads_build_pieces(rd, d_letters_ptr, d_loff.data(), d_namb.data());
 	const auto t_pack = now();
 	if (rc == 0)
 		rc = reads_finish(rd);

@@ -393,3 +393,74 @@ def test_degenerate_inputs(pg, oracle_bin, tmp_path):
         assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)])[0] == 0
         assert _blast_text(pg, db, rd, tmp_path, "deg_" + tag) == want.read_bytes(), tag
     assert (tmp_path / "mixed.oracle.tsv").read_bytes()     # the mixed case does find hits
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_PIECE_SEEDS", "5,6").split(",")])
+def test_reads_with_long_unknown_runs_are_searched_in_pieces(pg, oracle_bin, tmp_path, monkeypatch, seed):
+    """Reads holding a run of 6 or more non-ACGT letters (mates joined by N's, masked middles) are searched as the
+    stretches between the runs and put back together (engine.hpp: pgx_reads::pieces); the oracle searches them whole.
+    Runs of every length around the threshold, at the ends, several per read, both sides on one diagonal or not."""
+    import random
+    rng = random.Random(seed)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(900)) for _ in range(250)]
+    for i in range(0, 250, 9):  # near copies: several subjects per read, mismatches next to the runs
+        s = list(seqs[i - 1])
+        for p_ in rng.sample(range(900), 25):
+            s[p_] = rng.choice("ACGT")
+        seqs[i] = "".join(s)
+    db = tmp_path / "db.fa"
+    db.write_text("".join(">gi|%d|x|s%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+
+    def unknown(n):
+        return "".join(rng.choice("NNNNNRYKMSWBDHV") for _ in range(n))
+
+    reads = []
+    for i in range(700):
+        kind = i % 7
+        src = rng.choice(seqs)
+        if kind == 0:      # masked middle: both sides stay on one diagonal
+            L = rng.randint(120, 420)
+            o = rng.randrange(0, 900 - L)
+            w = list(src[o:o + L])
+            a = rng.randrange(0, L - 20)
+            k = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 30, 100])
+            w[a:a + k] = unknown(min(k, L - a))
+            r = "".join(w)
+        elif kind == 1:    # mates of one subject joined by a gap of another length than their distance
+            o1 = rng.randrange(0, 300)
+            o2 = o1 + rng.randint(150, 400)
+            r = src[o1:o1 + rng.randint(60, 150)] + "N" * rng.choice([5, 6, 7, 100, 189]) + src[o2:o2 + rng.randint(60, 150)]
+        elif kind == 2:    # mates of two subjects, reverse-complemented second mate
+            other = rng.choice(seqs)
+            m2 = other[100:100 + 130][::-1].translate(str.maketrans("ACGT", "TGCA"))
+            r = src[50:180] + "N" * rng.choice([6, 11, 100]) + m2
+        elif kind == 3:    # runs at the ends, short stretches between runs
+            core = src[200:200 + rng.randint(28, 200)]
+            r = unknown(rng.choice([0, 3, 6, 20])) + core + unknown(rng.choice([0, 5, 6, 40])) + src[500:500 + rng.choice([10, 27, 28, 60])] + unknown(rng.choice([0, 6]))
+        elif kind == 4:    # several runs, pieces with short runs inside
+            parts = []
+            for _ in range(rng.randint(2, 5)):
+                o = rng.randrange(0, 750)
+                p_ = list(src[o:o + rng.randint(20, 140)])
+                if rng.random() < 0.5 and len(p_) > 40:
+                    p_[rng.randrange(len(p_))] = "N"
+                parts.append("".join(p_))
+                parts.append(unknown(rng.choice([2, 5, 6, 7, 9, 15])))
+            r = "".join(parts[:-1])
+        elif kind == 5:    # nothing to find: only unknown letters, or stretches below a word
+            r = unknown(rng.choice([1, 5, 6, 40, 300])) if rng.random() < 0.5 else (src[0:20] + unknown(8) + src[40:67] + unknown(6) + src[100:110])
+        else:              # a plain read, and a long one (lazy class) with a run
+            if rng.random() < 0.5:
+                r = src[100:250]
+            else:
+                r = src[0:400] + unknown(50) + src[450:900]
+        reads.append(">q%d\n%s\n" % (i, r))
+    rd = tmp_path / "reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "want.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want),
+                    "-num_threads", "8"], timeout=900)[0] == 0
+    assert len(want.read_bytes()) > 50000
+    assert _blast_text(pg, db, rd, tmp_path, "pieces") == want.read_bytes()
+    monkeypatch.setenv("PGX_NO_PIECES", "1")
+    assert _blast_text(pg, db, rd, tmp_path, "whole") == want.read_bytes()

@@ -169,3 +169,35 @@ def test_ragged_lineages_and_repeated_rdp_triplets(pg, chain, tmp_path, oracle_b
     # and the file verb on the same tables
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
     assert (tmp_path / "c2.txt").read_bytes() == want
+
+
+def test_mate_joined_reads_through_the_fused_pipeline(pg, chain, tmp_path, oracle_bin):
+    """The shape Trim hands over (two mates joined by 100 N's): searched in pieces, ordered and voted on per joined
+    read; table and consensus text equal to the oracle chain run on the same FASTA."""
+    from pangea_plus_amd import _capi
+    lines = (chain / "reads.fa").read_text().split("\n")
+    names, seqs = lines[0::2], lines[1::2]
+    joined, keep = [], set()
+    for i in range(0, 1200, 2):
+        joined.append("%s\n%s%s%s\n" % (names[i], seqs[i][:130], "N" * 100, seqs[i + 1][:130]))
+        keep.add(names[i][1:].split()[0])
+    (tmp_path / "joined.fa").write_text("".join(joined))
+    rdp_lines = [l for l in (chain / "rdp.tsv").read_text().splitlines(True) if l.split("\t")[0] in keep]
+    assert len(rdp_lines) == len(keep)
+    (tmp_path / "rdp.tsv").write_text("".join(rdp_lines))
+    assert run_cmd([oracle_bin, "blastn", "-query", str(tmp_path / "joined.fa"), "-db", str(chain / "db.fa"), "-outfmt", "6", "-out",
+                    str(tmp_path / "hits.tsv"), "-num_threads", "8"], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "taxcollector", "-f", str(tmp_path / "hits.tsv"), "-o", str(tmp_path / "hits_class.tsv"), "-d",
+                    str(chain / "Tax_class")], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "consensus", "-b", str(tmp_path / "hits_class.tsv"), "-r", str(tmp_path / "rdp.tsv"), "-o",
+                    str(tmp_path / "consensus.txt")], timeout=600)[0] == 0
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
+    reads = pg.Reads.from_fasta(str(tmp_path / "joined.fa"))
+    rdp = pg.Rdp.from_file(str(tmp_path / "rdp.tsv"), reads, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    want_hits = (tmp_path / "hits.tsv").read_bytes()
+    assert len(want_hits) > 100000
+    assert hits.format(db, reads) == want_hits
+    assert _capi.consensus_format(db, reads, hits, recs) == (tmp_path / "consensus.txt").read_bytes()
