@@ -187,6 +187,9 @@ int pgx_synth_write_taxdump(const pgx_synth_cfg *cfg, const char *dir);
 
 typedef struct pgx_reads pgx_reads; /* a batch of reads resident in HBM, both strands packed */
 int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_reads **out);
+/* the same from FASTA text in memory (copied), e.g. pgx_trim_file's fasta_text: Trim -> Classify without the
+ * output_files/trim2/..._runblast.fasta file in between (README.md:34 -> :96) */
+int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64_t count, pgx_reads **out);
 int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, pgx_reads **out);
 void pgx_reads_close(pgx_reads *r);
 int64_t pgx_reads_count(const pgx_reads *r);

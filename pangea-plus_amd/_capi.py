@@ -89,7 +89,7 @@ SYMBOLS = [
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
-    "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_synth", "pgx_reads_close", "pgx_reads_count",
+    "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus",
@@ -116,6 +116,7 @@ def _declare(L):
     sig("pgx_hits_count", I64, [V])
     sig("pgx_reads_from_synth", C.c_int, [V, I64, I64, V])
     sig("pgx_reads_from_fasta", C.c_int, [S, I64, I64, V])
+    sig("pgx_reads_from_fasta_text", C.c_int, [C.c_char_p, C.c_size_t, I64, I64, V])
     sig("pgx_reads_get", C.c_int, [V, I64, V, I32, V])
     sig("pgx_hits_copy", C.c_int, [V, V, I64])
     sig("pgx_hits_read_offsets", C.c_int, [V, V, I64])
@@ -274,6 +275,13 @@ class Reads(_Handle):
     def from_fasta(cls, path, first=0, count=-1):
         p = C.c_void_p()
         _check(lib().pgx_reads_from_fasta(_b(path), first, count, C.byref(p)))
+        return cls(p)
+
+    @classmethod
+    def from_fasta_text(cls, text, first=0, count=-1):
+        """A batch from FASTA text in memory (bytes), e.g. the FASTA trim2() returns."""
+        p = C.c_void_p()
+        _check(lib().pgx_reads_from_fasta_text(text, len(text), first, count, C.byref(p)))
         return cls(p)
 
     def __len__(self):

@@ -1546,6 +1546,13 @@ int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_rea
 	return pgx::reads_from_fasta_ex(path, first, count, false, nullptr, out);
 }
 
+int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64_t count, pgx_reads **out)
+{
+	if ((!text && len) || !out)
+		return fail(PGX_E_ARG, "pgx_reads_from_fasta_text: null argument");
+	return pgx::reads_from_fasta_text(std::make_shared<const std::string>(text ? text : "", len), first, count, false, nullptr, out);
+}
+
 void pgx_reads_close(pgx_reads *r) { delete r; }
 int64_t pgx_reads_count(const pgx_reads *r) { return r ? r->n : 0; }
 

@@ -112,6 +112,11 @@ def test_trimmed_fasta_feeds_the_read_importer(tmp_path):
     (tmp_path / "reads.fa").write_bytes(fasta)
     reads = pg.Reads.from_fasta(str(tmp_path / "reads.fa"))
     assert len(reads) == 5000
+    # and without the file in between: same batch from the text in memory
+    direct = pg.Reads.from_fasta_text(fasta)
+    assert len(direct) == 5000
+    for i in (0, 1, 77, 4999):
+        assert (direct.get(i) == reads.get(i)).all()
 
 
 def test_fasta_input_and_negative_truncate_are_declined(tmp_path):
