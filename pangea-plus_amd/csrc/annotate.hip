@@ -9,6 +9,7 @@
 //                           logic over the two files is control flow on ids (host); agreement counting and
 //                           the order-dependent arg-max run on the device (consensus_core.hpp)
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <map>
 
@@ -617,59 +618,81 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open RDP file %s", path);
 	const size_t n = (size_t)reads->n;
-	std::vector<uint32_t> off(n + 1, 0), name;
+	std::vector<uint32_t> off(n + 1, 0), name, trips(n ? n : 1, 0);
 	std::vector<int8_t> rank;
 	std::vector<uint8_t> present(n ? n : 1, 0);
-	std::vector<std::vector<std::pair<uint32_t, int8_t>>> per(n);
+	std::vector<uint32_t> code;
+	// A line belongs to the first read at or after the cursor that carries its name (the streams are in the same
+	// order; names may repeat).  The reads are indexed by name hash so that a line of a read that is not in this
+	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.
+	const ReadNameIndex index(*reads);
+	// the few distinct name / rank texts of an RDP file are cleaned and interned once each
+	struct Memo {
+		std::unordered_map<uint64_t, std::vector<std::pair<std::string, uint32_t>>> m;
+		uint32_t get(const char *p, size_t len, const std::function<uint32_t(const std::string &)> &make)
+		{
+			auto &v = m[fnv64_bytes(p, len)];
+			for (auto &e : v)
+				if (e.first.size() == len && memcmp(e.first.data(), p, len) == 0)
+					return e.second;
+			v.emplace_back(std::string(p, len), make(std::string(p, len)));
+			return v.back().second;
+		}
+	} names, ranks;
+	static const char kFive[] = "\t\t\t\t\t";
 	size_t cursor = 0;
+	const char *base = text.data();
 	for (size_t s = 0; s < text.size();) {
-		size_t e = text.find('\n', s);
-		if (e == std::string::npos)
-			e = text.size();
-		std::string line(text, s, e - s);
+		const char *nl = (const char *)memchr(base + s, '\n', text.size() - s);
+		const size_t e = nl ? (size_t)(nl - base) : text.size();
+		const char *line = base + s;
+		const size_t len = e - s;
 		s = e + 1;
-		size_t five = line.find("\t\t\t\t\t");
-		std::string id = five == std::string::npos ? line : line.substr(0, five);
-		size_t r = cursor;
-		while (r < n && reads->name_of((int64_t)r) != id)
-			r++;
+		const char *five = (const char *)memmem(line, len, kFive, 5);
+		const size_t id_len = five ? (size_t)(five - line) : len;
+		const size_t r = index.find(line, id_len, cursor);
 		if (r >= n)
 			continue; // an RDP line for a read that is not in this batch
 		cursor = r + 1;
 		present[r] = 1;
-		if (five == std::string::npos)
+		if (!five)
 			continue;
-		std::string rest = line.substr(five + 5);
-		size_t again = rest.find("\t\t\t\t\t");
-		if (again != std::string::npos)
-			rest.resize(again);
-		std::vector<std::string> f;
-		for (size_t a = 0; a <= rest.size();) {
-			size_t t = rest.find('\t', a);
-			if (t == std::string::npos)
-				t = rest.size();
-			f.emplace_back(rest, a, t - a);
-			a = t + 1;
+		const char *rest = five + 5;
+		size_t rest_len = len - id_len - 5;
+		if (const char *again = (const char *)memmem(rest, rest_len, kFive, 5))
+			rest_len = (size_t)(again - rest);
+		while (rest_len && rest[rest_len - 1] == '\t') // trailing empty fields are dropped
+			rest_len--;
+		// fields in threes: name, rank, confidence
+		size_t a = 0;
+		for (int k = 0; a <= rest_len && (rest_len || k == 0); k++) {
+			const char *t = (const char *)memchr(rest + a, '\t', rest_len - a);
+			const size_t fe = t ? (size_t)(t - rest) : rest_len;
+			if (k % 3 == 0) {
+				if (rest_len == 0)
+					break;
+				name.push_back(names.get(rest + a, fe - a, [&](const std::string &raw) { return db->intern(clean_rdp_name(raw)); }));
+				rank.push_back((int8_t)-1);
+				trips[r]++;
+			} else if (k % 3 == 1) {
+				rank.back() = (int8_t)ranks.get(rest + a, fe - a, [&](const std::string &raw) { return (uint32_t)(uint8_t)rdp_rank_index(raw); });
+			}
+			if (!t)
+				break;
+			a = fe + 1;
 		}
-		while (!f.empty() && f.back().empty())
-			f.pop_back();
-		for (size_t b = 0; b < f.size(); b += 3)
-			per[r].emplace_back(db->intern(clean_rdp_name(f[b])), b + 1 < f.size() ? rdp_rank_index(f[b + 1]) : (int8_t)-1);
 	}
-	std::vector<uint32_t> code;
-	for (size_t r = 0; r < n; r++) {
-		for (auto &p : per[r]) {
-			name.push_back(p.first);
-			rank.push_back(p.second);
-			code.push_back((p.first << 3) | (uint32_t)(p.second + 1));
-		}
-		off[r + 1] = (uint32_t)name.size();
-	}
+	// matched reads come in increasing order, so the triplets already lie in read order
+	code.resize(name.size());
+	for (size_t k = 0; k < name.size(); k++)
+		code[k] = (name[k] << 3) | (uint32_t)(rank[k] + 1);
+	for (size_t r = 0; r < n; r++)
+		off[r + 1] = off[r] + trips[r];
 	pgx_rdp *rd = new pgx_rdp();
 	rd->n = (int64_t)n;
 	rd->max_trip = 0;
 	for (size_t r = 0; r < n; r++)
-		rd->max_trip = std::max(rd->max_trip, (int)std::min<size_t>(per[r].size(), 8));
+		rd->max_trip = std::max(rd->max_trip, (int)std::min<uint32_t>(trips[r], 8));
 	int rc = rd->d_off.alloc(n + 1);
 	if (rc == 0) rc = rd->d_off.upload(off.data(), n + 1);
 	if (rc == 0) rc = rd->d_name.alloc(name.size() ? name.size() : 1);

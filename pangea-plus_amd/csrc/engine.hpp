@@ -118,6 +118,85 @@ struct pgx_rdp {
 
 namespace pgx {
 
+inline uint64_t fnv64_bytes(const char *p, size_t n)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < n; i++)
+		h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+	return h;
+}
+
+// Reads of a batch by name: open-addressing table of name hashes, reads with one hash chained in ascending order.
+// find() = the first read at or after `from` whose name is the given text, or n when there is none.
+struct ReadNameIndex {
+	const pgx_reads &rd;
+	std::vector<uint32_t> slot, next; // slot: first read of a hash (+1, 0 = empty); next: following read of the same hash (+1)
+	std::vector<uint64_t> hash;
+	uint64_t mask = 0;
+	bool unique = true; // no two reads share a name
+	explicit ReadNameIndex(const pgx_reads &r) : rd(r)
+	{
+		const size_t n = (size_t)rd.n;
+		size_t cap = 16;
+		while (cap < 2 * n + 1)
+			cap <<= 1;
+		mask = cap - 1;
+		slot.assign(cap, 0);
+		next.assign(n, 0);
+		hash.resize(n);
+		std::vector<uint32_t> last(cap, 0);
+		std::string tmp;
+		for (size_t i = 0; i < n; i++) {
+			const char *p;
+			size_t len;
+			name_span(i, tmp, &p, &len);
+			const uint64_t h = hash[i] = fnv64_bytes(p, len);
+			size_t k = (size_t)(h & mask);
+			while (slot[k] && hash[slot[k] - 1] != h)
+				k = (k + 1) & mask;
+			if (!slot[k]) {
+				slot[k] = (uint32_t)i + 1;
+			} else {
+				next[last[k] - 1] = (uint32_t)i + 1;
+				unique = false; // (or two names with one 64-bit hash: the callers only lose a shortcut)
+			}
+			last[k] = (uint32_t)i + 1;
+		}
+	}
+	void name_span(size_t i, std::string &tmp, const char **p, size_t *len) const
+	{
+		if (rd.synthetic) {
+			tmp = rd.name_of((int64_t)i);
+			*p = tmp.data();
+			*len = tmp.size();
+		} else {
+			*p = rd.h_text->data() + rd.name_off[i];
+			*len = rd.name_len[i];
+		}
+	}
+	size_t find(const char *text, size_t len, size_t from) const
+	{
+		const size_t n = (size_t)rd.n;
+		if (n == 0)
+			return n;
+		const uint64_t h = fnv64_bytes(text, len);
+		size_t k = (size_t)(h & mask);
+		while (slot[k] && hash[slot[k] - 1] != h)
+			k = (k + 1) & mask;
+		std::string tmp;
+		for (uint32_t i = slot[k]; i; i = next[i - 1]) {
+			if ((size_t)(i - 1) < from)
+				continue;
+			const char *p;
+			size_t l;
+			name_span(i - 1, tmp, &p, &l);
+			if (l == len && memcmp(p, text, len) == 0)
+				return i - 1;
+		}
+		return n;
+	}
+};
+
 // seqdb.hip
 int db_upload_and_index(pgx_db *db);
 int db_build_blk_info(pgx_db *db);

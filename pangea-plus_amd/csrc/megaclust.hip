@@ -542,7 +542,7 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
 	// query texts: a pair (OTU, query) counts once; only repeated read names need the key sort
 	bool unique_queries = true;
 	std::vector<uint32_t> qid;
-	if (!reads->synthetic && !p.count_all) {
+	if (!reads->synthetic && !p.count_all && !ReadNameIndex(*reads).unique) {
 		std::unordered_map<std::string, uint32_t> qmap;
 		std::vector<std::string> qtext;
 		qid.resize((size_t)n);
