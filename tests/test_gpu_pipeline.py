@@ -201,3 +201,32 @@ def test_mate_joined_reads_through_the_fused_pipeline(pg, chain, tmp_path, oracl
     assert len(want_hits) > 100000
     assert hits.format(db, reads) == want_hits
     assert _capi.consensus_format(db, reads, hits, recs) == (tmp_path / "consensus.txt").read_bytes()
+
+
+def test_rdp_lines_of_other_reads_and_repeated_names(pg, chain, tmp_path):
+    """An RDP file may hold lines of reads that are not in the batch (another shard of the run): they are skipped,
+    one probe each.  A name carried by two reads takes the lines of that name in order."""
+    from pangea_plus_amd import _capi
+    lines = (chain / "reads.fa").read_text().split("\n")
+    names, seqs = lines[0::2], lines[1::2]
+    sub = "".join("%s\n%s\n" % (names[i], seqs[i]) for i in range(0, 2000, 2))
+    sub += "%s\n%s\n" % (names[10], seqs[11])                 # the name of read 10 once more, other bases
+    (tmp_path / "sub.fa").write_text(sub)
+    rdp_all = (chain / "rdp.tsv").read_text().splitlines(True)
+    by_name = {l.split("\t")[0]: l for l in rdp_all}
+    own = [by_name[names[i][1:]] for i in range(0, 2000, 2)] + [by_name[names[11][1:]].replace(names[11][1:], names[10][1:], 1)]
+    (tmp_path / "own.tsv").write_text("".join(own))
+    # the whole stream (4000 lines, reads of other shards between the batch's own) plus the second line of the repeated name
+    (tmp_path / "all.tsv").write_text("".join(rdp_all) + own[-1])
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
+    reads = pg.Reads.from_fasta(str(tmp_path / "sub.fa"))
+    assert len(reads) == 1001
+    got = []
+    for f in ("own.tsv", "all.tsv"):
+        rdp = pg.Rdp.from_file(str(tmp_path / f), reads, db)
+        hits, recs = _capi.classify_consensus(db, reads, rdp)
+        got.append((hits.format(db, reads), _capi.consensus_format(db, reads, hits, recs), recs.copy()))
+    assert got[0][0] == got[1][0] and got[0][1] == got[1][1] and (got[0][2] == got[1][2]).all()
+    assert len(got[0][1]) > 20000
