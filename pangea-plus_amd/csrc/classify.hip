@@ -327,6 +327,30 @@ constexpr int kQueue = 64 * (kDeal + 1); // candidate queue per wave (filled 64*
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
+// hit records are written once and read once by the next kernel: streamed past the caches (the database words,
+// block records and subject records are what should stay in them)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+union HitWords {
+	pgx_hit h;
+	u32x4 v[2];
+};
+__device__ __forceinline__ void store_hit_stream(pgx_hit *p, const pgx_hit &h)
+{
+	HitWords w;
+	w.h = h;
+	u32x4 *d = reinterpret_cast<u32x4 *>(p);
+	__builtin_nontemporal_store(w.v[0], d);
+	__builtin_nontemporal_store(w.v[1], d + 1);
+}
+__device__ __forceinline__ pgx_hit load_hit_stream(const pgx_hit *p)
+{
+	HitWords w;
+	const u32x4 *s = reinterpret_cast<const u32x4 *>(p);
+	w.v[0] = __builtin_nontemporal_load(s);
+	w.v[1] = __builtin_nontemporal_load(s + 1);
+	return w.h;
+}
+
 
 constexpr int kDiagSlots = 128;       // open-addressed set of (diagonal, strand) keys per read
 constexpr int kDiagProbes = 8;
@@ -712,8 +736,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				}
 				if (ok) {
 					uint32_t b = seed_bucket(window16(rw, qpos), db.bits);
-					lo = db.bucket_off[b];
-					cnt = db.bucket_off[(uint64_t)b + 1] - lo;
+					lo = __builtin_nontemporal_load(&db.bucket_off[b]);
+					cnt = __builtin_nontemporal_load(&db.bucket_off[(uint64_t)b + 1]) - lo;
 				}
 				n_probe++;
 			}
@@ -769,9 +793,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 					ctx[u] = make_uint2(0u, 0u);
 					if (active[u]) {
 						// posting and its context in one 12-byte record
-						const uint3 rec = db.post_ctx[pidx[u]];
-						raw[u] = rec.x;
-						ctx[u] = make_uint2(rec.y, rec.z);
+						const uint32_t *rp = reinterpret_cast<const uint32_t *>(db.post_ctx + pidx[u]);
+						raw[u] = __builtin_nontemporal_load(rp);
+						ctx[u] = make_uint2(__builtin_nontemporal_load(rp + 1), __builtin_nontemporal_load(rp + 2));
 					}
 				}
 				// stage 2: the 13 database bases left and the 12 right of the 16-mer (post_ctx, fetched beside
@@ -1322,7 +1346,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 		}
 		if (mine)
-			hits[o + rank] = h;
+			store_hit_stream(hits + o + rank, h);
 		if (!do_consensus || cv.dbg == 3)
 			continue;
 		uint32_t rmv = 0, ntok = 0, sim = 0;
