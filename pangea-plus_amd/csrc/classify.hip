@@ -327,7 +327,7 @@ constexpr int kQueue = 64 * (kDeal + 1); // candidate queue per wave (filled 64*
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
-// hit records are written once and read once by the next kernel: streamed past the caches (the database words,
+// the ordered hit table is written once and read by a later call: streamed past the caches (the database words,
 // block records and subject records are what should stay in them)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 union HitWords {
@@ -341,14 +341,6 @@ __device__ __forceinline__ void store_hit_stream(pgx_hit *p, const pgx_hit &h)
 	u32x4 *d = reinterpret_cast<u32x4 *>(p);
 	__builtin_nontemporal_store(w.v[0], d);
 	__builtin_nontemporal_store(w.v[1], d + 1);
-}
-__device__ __forceinline__ pgx_hit load_hit_stream(const pgx_hit *p)
-{
-	HitWords w;
-	const u32x4 *s = reinterpret_cast<const u32x4 *>(p);
-	w.v[0] = __builtin_nontemporal_load(s);
-	w.v[1] = __builtin_nontemporal_load(s + 1);
-	return w.h;
 }
 
 
@@ -456,7 +448,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		return;
 	}
 
-	int pos, run_start;
+	int pos, run_start = 0; // (run_start is set by the branch that owns it: whole diagonals only exist for masks with windows)
 	typename Mask::Win W;
 	bool whole = false;
 	if constexpr (Mask::kHasWindows)
@@ -1144,7 +1136,6 @@ __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t su
 	}
 	const uint4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
 	const uint32_t pr[15] = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
-	uint32_t rm = 0;
 	// the compare grid: 7 pairs x 6 triplets for the usual seven-rank lineages (one kernel-uniform branch), 15 x 8 otherwise
 	if (cv.np_max <= 7 && cv.nr_max <= 6)
 		return pair_grid<7, 6>(pr, rc, np);
