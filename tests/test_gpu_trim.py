@@ -8,6 +8,7 @@ import pytest
 
 from conftest import ROOT, run_cmd
 from test_oracle_trim import run_trim_case, trim_cases
+from trim_inputs import damaged as _messy, fastq_text, qseq_text, random_case
 
 pytestmark = pytest.mark.gpu
 
@@ -17,48 +18,6 @@ BIN = os.path.join(ROOT, "pangea-plus_amd", "bin")
 @pytest.mark.parametrize("name,info", trim_cases())
 def test_trim2_cli_matches_reference(name, info, tmp_path):
     run_trim_case([os.path.join(BIN, "trim2")], name, info, tmp_path)
-
-
-def quality_string(rng, n, base):
-    """One of the shapes the running-sum rule distinguishes: clean, tail drop, noise, dips, all low, near the cutoff."""
-    kind = rng.randrange(6)
-    if kind == 0:
-        q = [rng.randint(30, 40) for _ in range(n)]
-    elif kind == 1:
-        cut = rng.randint(n // 2, n)
-        q = [rng.randint(30, 40) if j < cut else rng.randint(2, 10) for j in range(n)]
-    elif kind == 2:
-        q = [rng.randint(2, 40) for _ in range(n)]
-    elif kind == 3:
-        step = rng.randint(7, 40)
-        q = [2 if j % step == 0 else 38 for j in range(n)]
-    elif kind == 4:
-        q = [rng.randint(2, 12) for _ in range(n)]
-    else:
-        q = [20 + rng.choice((-2, -1, 0, 1, 2)) for _ in range(n)]
-    return "".join(chr(base + v) for v in q)
-
-
-def fastq_text(seed, n, lmin, lmax):
-    rng = random.Random(seed)
-    out = []
-    for i in range(n):
-        L = rng.randint(lmin, lmax)
-        seq = "".join(rng.choice("ACGTN" if i % 17 == 0 else "ACGT") for _ in range(L))
-        out.append("@M%d:%d@%d extra\n%s\n+\n%s\n" % (seed, i, i % 7, seq, quality_string(rng, L, 33)))
-    return "".join(out).encode("latin-1")
-
-
-def qseq_text(seed, n, lmin, lmax):
-    rng = random.Random(seed)
-    a, b = [], []
-    for i in range(n):
-        xy = [str(rng.randint(1, 8)), str(rng.randint(1101, 2316)), str(rng.randint(1000, 20000)), str(rng.randint(1000, 20000))]
-        for mate, dst in ((1, a), (2, b)):
-            L = rng.randint(lmin, lmax)
-            seq = "".join(rng.choice("ACGT.") if rng.random() < 0.02 else rng.choice("ACGT") for _ in range(L))
-            dst.append("\t".join(["HWI-X", "12"] + xy + ["TTAGGC", str(mate), seq, quality_string(rng, L, 64), rng.choice("01")]) + "\n")
-    return "".join(a).encode("latin-1"), "".join(b).encode("latin-1")
 
 
 def oracle_trim(oracle_bin, work, argv):
@@ -181,3 +140,23 @@ def test_trimmed_pairs_through_blastn_equal_the_oracle_chain(oracle_bin, tmp_pat
         right = any(int(h[6]) >= 200 for h in own)
         both += left and right
     assert both > 0.9 * n_reads
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_TRIM_SEEDS", "31,32,33").split(",")])
+def test_trim_random_files_and_options_equal_oracle(seed, oracle_bin, tmp_path):
+    import pangea_plus_amd as pg
+    pg.init(0)
+    a, b, g, t = random_case(seed, 3000, 2500)
+    (tmp_path / "a.txt").write_bytes(a)
+    argv = ["-a", "a.txt"]
+    if b is not None:
+        (tmp_path / "b.txt").write_bytes(b)
+        argv += ["-b", "b.txt"]
+    if g is not None:
+        argv += ["-g", g]
+    if t is not None:
+        argv += ["-t", t]
+    want_out, want_fasta = oracle_trim(oracle_bin, tmp_path, argv)
+    messages, fasta, mode = pg.trim2(str(tmp_path / "a.txt"), b=str(tmp_path / "b.txt") if b is not None else None, g=g, t=t)
+    assert fasta == want_fasta
+    assert (fasta + messages if mode == pg._capi.TRIM_FASTQ else messages) == want_out
