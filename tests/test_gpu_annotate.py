@@ -165,3 +165,27 @@ def test_consensus_random_tables_match_oracle(pg, oracle_bin, tmp_path):
     assert rc == 0
     assert (tmp_path / "p.txt").read_bytes() == (tmp_path / "o.txt").read_bytes()
     assert log.replace(str(tmp_path / "p.txt").encode(), b"@") == so.replace(str(tmp_path / "o.txt").encode(), b"@")
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_TAX_SEEDS", "1,2,3,4,5,6").split(",")])
+def test_taxcollector_random_taxonomies_match_oracle(pg, oracle_bin, tmp_path, seed):
+    """Random irregular trees (any mix of ranks, several names per node, gi numbers without a node): the same generator
+    the oracle is cross-checked with against the reference's C + Perl (oracle/sweep_taxcollect_vs_reference.py).  Where
+    the reference never terminates both report it and have written the same lines before."""
+    from tax_inputs import hits, taxonomy, write_dumps
+    rng = random.Random(seed)
+    nodes, names, gis = taxonomy(rng)
+    d = tmp_path / "Tax_class"
+    d.mkdir()
+    write_dumps(str(d), nodes, names, gis)
+    pg.TaxDb.create(str(d))
+    (tmp_path / "in.tsv").write_text(hits(rng, gis))
+    rc, so, _ = run_cmd([oracle_bin, "taxcollector", "-f", str(tmp_path / "in.tsv"), "-o", str(tmp_path / "o.tsv"), "-d", str(d)])
+    if rc == 0:
+        rep = pg.taxcollector(str(tmp_path / "in.tsv"), str(tmp_path / "p.tsv"), taxdir=str(d))
+        assert rep == so
+    else:
+        with pytest.raises(pg.PangeaError) as e:
+            pg.taxcollector(str(tmp_path / "in.tsv"), str(tmp_path / "p.tsv"), taxdir=str(d))
+        assert e.value.status == -6
+    assert (tmp_path / "p.tsv").read_bytes() == (tmp_path / "o.tsv").read_bytes()
