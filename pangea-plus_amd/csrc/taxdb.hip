@@ -298,16 +298,24 @@ int tax_node_record(const pgx_taxdb *db, int taxid, pgx_node *out)
 }
 
 // names lookup with the reference's exact probing order (ncbitc.c:647-699): the bisection runs
-// over positions 0..num-1 while records are numbered 1..num, so the last record is never found
-int tax_names_lookup(const pgx_taxdb *db, int taxid, std::vector<const uint8_t *> &out)
+// over positions 0..num-1 while records are numbered 1..num, so the last record is never found; and a
+// search that probes position 0 (a negative file offset: ncbitc_seek_name closes the file, :637-640, and every
+// later seek fails on the closed stream) finds nothing from then on — whether `-n 1` gets there depends on the
+// number of records.  `failed_seeks` = the perror lines the reference prints in such a search.
+int tax_names_lookup(const pgx_taxdb *db, int taxid, std::vector<const uint8_t *> &out, int *failed_seeks)
 {
+	if (failed_seeks)
+		*failed_seeks = 0;
 	if (!db->have_names)
 		return -1;
 	const int num = db->n_names;
 	const uint8_t *cur = nullptr;
+	int closed = 0;
 	auto seek = [&](int pos) -> int {
-		if (pos <= 0)
+		if (closed || pos <= 0) {
+			closed++;
 			return -1;
+		}
 		if ((size_t)(pos - 1) < db->names_records)
 			cur = db->names.data() + 4 + (size_t)(pos - 1) * 196;
 		return cur ? rd32(cur) : 0;
@@ -326,6 +334,8 @@ int tax_names_lookup(const pgx_taxdb *db, int taxid, std::vector<const uint8_t *
 		else
 			hi = j - 1;
 	}
+	if (failed_seeks)
+		*failed_seeks = closed;
 	if (!hit)
 		return 0;
 	int i;
@@ -712,7 +722,10 @@ int pgx_tax_cli(int argc, char **argv, const char *dir, char **out_text, char **
 		}
 	} else if (verb == 'n') {
 		std::vector<const uint8_t *> recs;
-		int rc = tax_names_lookup(db, tax_id, recs);
+		int failed_seeks = 0;
+		int rc = tax_names_lookup(db, tax_id, recs, &failed_seeks);
+		for (int k = 0; k < failed_seeks; k++)
+			err.s += k == 0 ? "fseek: Invalid argument\n" : "fseek: Bad file descriptor\n";
 		if (rc < 0)
 			lookup_failed(-1);
 		else if (rc == 0)

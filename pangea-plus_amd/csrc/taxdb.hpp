@@ -24,7 +24,7 @@ namespace pgx {
 const char *tax_rank_text(int id);
 int8_t driver_rank_code(int rank_enum);
 int tax_node_record(const pgx_taxdb *db, int taxid, pgx_node *out);
-int tax_names_lookup(const pgx_taxdb *db, int taxid, std::vector<const uint8_t *> &out);
+int tax_names_lookup(const pgx_taxdb *db, int taxid, std::vector<const uint8_t *> &out, int *failed_seeks = nullptr);
 bool tax_scientific_name(const pgx_taxdb *db, int taxid, std::string &name);
 int tax_walk_device(pgx_taxdb *db, const int32_t *d_gi, int64_t n, int32_t *d_lineage, int32_t *d_count,
 		    int32_t *d_status, int32_t *d_leaf);

@@ -189,3 +189,28 @@ def test_taxcollector_random_taxonomies_match_oracle(pg, oracle_bin, tmp_path, s
             pg.taxcollector(str(tmp_path / "in.tsv"), str(tmp_path / "p.tsv"), taxdir=str(d))
         assert e.value.status == -6
     assert (tmp_path / "p.tsv").read_bytes() == (tmp_path / "o.tsv").read_bytes()
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_TAX_SEEDS", "1,2,3,4,5,6").split(",")])
+def test_tax_class_cli_on_random_taxonomies_matches_oracle(oracle_bin, tmp_path, seed):
+    """`tax_class -c` and every `-s/-g/-t/-n` lookup on a random taxonomy: the oracle is cross-checked against the
+    reference's own C on the same generator (oracle/sweep_tax_class_vs_reference.py), incl. the name searches that
+    probe position 0 of names.dmp.bin (the reference closes its file there and finds nothing afterwards)."""
+    from tax_inputs import taxonomy, write_dumps
+    rng = random.Random(seed)
+    nodes, names, gis = taxonomy(rng)
+    dirs = []
+    for tool in ("product", "oracle"):
+        d = tmp_path / tool
+        d.mkdir()
+        write_dumps(str(d), nodes, names, gis)
+        dirs.append(d)
+    cmds = ([os.path.join(BIN, "tax_class")], [oracle_bin, "tax_class"])
+    assert run_cmd(cmds[0] + ["-c"], cwd=dirs[0])[0] == 0 and run_cmd(cmds[1] + ["-c"], cwd=dirs[1])[0] == 0
+    for n in ("gi_taxid_nucl.dmp.bin", "nodes.dmp.bin", "names.dmp.bin"):
+        assert (dirs[0] / n).read_bytes() == (dirs[1] / n).read_bytes(), n
+    queries = [["-s", str(g)] for g, _ in gis] + [["-g", str(g)] for g, _ in gis[:8]] + [["-s", "0"], ["-g", "0"], ["-s", str(gis[-1][0] + 5)]]
+    queries += [["-t", str(t)] for t, _, _, _ in nodes] + [["-n", str(t)] for t, _, _, _ in nodes] + [["-t", "9999"], ["-n", "9999"], ["-n", "5"]]
+    for q in queries:
+        a, b = run_cmd(cmds[0] + q, cwd=dirs[0]), run_cmd(cmds[1] + q, cwd=dirs[1])
+        assert (a[0], a[1], bool(a[2])) == (b[0], b[1], bool(b[2])), q
