@@ -5,7 +5,7 @@
 //   k_nl_count / k_nl_write   line index of the text (one start offset per line), 16 KB tiles, two passes
 //   k_fq_measure / k_qs_measure   one lane per output record: the script's running-sum quality rule
 //                                 (trim2.4.pl:543-563, :272-287), the kept span of each mate, the record's output size
-//   k_fq_emit / k_qs_emit     one wavefront per record writes its FASTA text (header rewrite, white-space removal,
+//   k_fq_emit / k_qs_emit     16 lanes per record write its FASTA text (header rewrite, white-space removal,
 //                             '.' -> N, the $GAPSIZE N's between mates) at the offset an exclusive scan gave it
 // The host keeps what the script does before it reads a record: getopts, the open checks, format detection on
 // the first line, and the messages.  What the script's Perl actually computes (several statements have no
@@ -177,14 +177,18 @@ __device__ uint64_t quality_end(const uint8_t *__restrict__ text, uint64_t off, 
 	return end;
 }
 
-// ------------------------------------------------------------------------------------------------- wave writers
-// `pos` is wave-uniform; every lane of the wavefront calls these together
+// ------------------------------------------------------------------------------------------------- group writers
+// A record is written by a group of kGroup = 16 lanes (four records per wavefront in flight: the writers wait on a
+// chain of dependent loads per record, more records per wavefront hide it).  `pos` is uniform within a group; the
+// lanes of a group call these together (groups of one wavefront may be in different calls or iterations).
+constexpr int kGroup = 16;
+
 template <typename Keep, typename Map>
 __device__ __forceinline__ void w_copy(char *__restrict__ out, uint64_t &pos, const uint8_t *__restrict__ src, uint64_t n, Keep keep, Map map)
 {
-	const int lane = threadIdx.x & 63;
-	const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-	for (uint64_t base = 0; base < n; base += 64) {
+	const int lane = threadIdx.x & (kGroup - 1), shift = (threadIdx.x & 63) & ~(kGroup - 1);
+	const uint32_t lt = (1u << lane) - 1u;
+	for (uint64_t base = 0; base < n; base += kGroup) {
 		const uint64_t i = base + lane;
 		uint8_t c = 0;
 		bool k = false;
@@ -192,23 +196,23 @@ __device__ __forceinline__ void w_copy(char *__restrict__ out, uint64_t &pos, co
 			c = src[i];
 			k = keep(c);
 		}
-		const unsigned long long m = __ballot(k);
+		const uint32_t m = (uint32_t)(__ballot(k) >> shift) & ((1u << kGroup) - 1u);
 		if (k)
-			out[pos + __popcll(m & lt)] = (char)map(c);
-		pos += (uint64_t)__popcll(m);
+			out[pos + __popc(m & lt)] = (char)map(c);
+		pos += (uint64_t)__popc(m);
 	}
 }
 
 __device__ __forceinline__ void w_fill(char *__restrict__ out, uint64_t &pos, char c, uint64_t n)
 {
-	for (uint64_t i = threadIdx.x & 63; i < n; i += 64)
+	for (uint64_t i = threadIdx.x & (kGroup - 1); i < n; i += kGroup)
 		out[pos + i] = c;
 	pos += n;
 }
 
 __device__ __forceinline__ void w_lit(char *__restrict__ out, uint64_t &pos, const char *lit, int n)
 {
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & (kGroup - 1);
 	if (lane < n)
 		out[pos + lane] = lit[lane];
 	pos += (uint64_t)n;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void k_fq_measure(TextView t, uint64_t n_rec, 
 	out_len[r] = len;
 }
 
-// the FASTA text of record `r`, written by one wavefront (trim2.4.pl:487-515)
+// the FASTA text of record `r`, written by one lane group (trim2.4.pl:487-515)
 __device__ void fq_emit_record(const TextView &t, uint64_t r, int paired, uint64_t gap, const FqRec f, uint64_t pos, char *__restrict__ out)
 {
 	const uint64_t l0 = r * (paired ? 8 : 4);
@@ -291,12 +295,12 @@ __device__ void fq_emit_record(const TextView &t, uint64_t r, int paired, uint64
 	w_lit(out, pos, "\n", 1);
 }
 
-// a bounded grid of wavefronts strides over the records
+// a bounded grid of lane groups strides over the records
 __global__ __launch_bounds__(256) void k_fq_emit(TextView t, uint64_t n_rec, int paired, uint64_t gap, const FqRec *__restrict__ rec,
 						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
 {
-	const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x / 64);
-	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += waves)
+	const uint64_t groups = (uint64_t)gridDim.x * (blockDim.x / kGroup);
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup; r < n_rec; r += groups)
 		fq_emit_record(t, r, paired, gap, rec[r], out_off[r], out);
 }
 
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void k_qs_measure(TextView a, TextView b, uint
 	out_len[r] = len;
 }
 
-// the FASTA text of pair `r`, written by one wavefront (trim2.4.pl:218-245)
+// the FASTA text of pair `r`, written by one lane group (trim2.4.pl:218-245)
 __device__ void qs_emit_record(const TextView &a, const TextView &b, uint64_t r, uint64_t gap, const QsRec q, uint64_t pos, char *__restrict__ out)
 {
 	const bool dots = (q.pad_dots & 16u) != 0;
@@ -427,8 +431,8 @@ __device__ void qs_emit_record(const TextView &a, const TextView &b, uint64_t r,
 __global__ __launch_bounds__(256) void k_qs_emit(TextView a, TextView b, uint64_t n_rec, uint64_t gap, const QsRec *__restrict__ rec,
 						 const uint64_t *__restrict__ out_off, char *__restrict__ out)
 {
-	const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x / 64);
-	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < n_rec; r += waves)
+	const uint64_t groups = (uint64_t)gridDim.x * (blockDim.x / kGroup);
+	for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / kGroup) + threadIdx.x / kGroup; r < n_rec; r += groups)
 		if (out_off[r + 1] != out_off[r]) // else a mate did not survive: nothing is written for the pair (:199-210)
 			qs_emit_record(a, b, r, gap, rec[r], out_off[r], out);
 }
@@ -503,7 +507,7 @@ static int upload_lines(const std::string &s, DeviceText &d)
 }
 
 // blocks of four wavefronts for the record writers: enough to fill 256 CUs several times over
-static unsigned emit_grid(uint64_t n_rec) { return (unsigned)std::min<uint64_t>((n_rec + 3) / 4, 256u * 32u); }
+static unsigned emit_grid(uint64_t n_rec) { return (unsigned)std::min<uint64_t>((n_rec + 256 / kGroup - 1) / (256 / kGroup), 256u * 32u); }
 
 static int take_output(const DevBuf<char> &out, uint64_t total, char **text, size_t *len)
 {
