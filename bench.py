@@ -199,6 +199,21 @@ def main():
                         traffic = None  # the counter figure is for the default launch only
                 except Exception:
                     traffic = None
+            # the roof of the kernel's access shape, measured here and now: 64-byte lines per second for random 8-byte
+            # lane loads over a 16 GiB table (pgx_probe_gather), against the kernel's L2 requests per second (requests
+            # per read from the PMC passes of profiles/, x reads, / measured kernel time)
+            line_roof = None
+            try:
+                lps, pms = C.c_double(), C.c_double()
+                _capi._check(pg.lib().pgx_probe_gather(16 << 30, 0, C.byref(lps), C.byref(pms)))
+                per_read = json.load(open(tp)).get("k_seed_extend_l2_requests_per_read")
+                if per_read and lps.value > 0:
+                    req = per_read * B * args.steps / (kernel_ms * 1e-3)
+                    line_roof = {"roof_lines_per_s": lps.value, "roof_as_GBps_of_64B_lines": lps.value * 64 / 1e9,
+                                 "kernel_l2_requests_per_s": req, "frac": req / lps.value,
+                                 "basis": "random 8-byte lane loads, 16 GiB table, 8 loads in flight per lane; kernel requests = %.1f per read (TCC_HIT+TCC_MISS, profiles/traffic.json)" % per_read}
+            except Exception as e:  # an older library without the probe: the line is still printed
+                line_roof = {"error": str(e)}
             out = {
                 "metric": "classified reads/sec (+ HBM GB/s fraction), 150 bp vs 1 Gbp db, 1/2/4/8 GPU",
                 "value": world * B * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
@@ -213,7 +228,8 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_seed_extend", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "alg_bytes_per_launch": alg_bytes / args.steps, "kernel_ms_per_launch": kernel_ms / args.steps,
-                             "survey_8d": survey_8d(last.hits / B, world * B * args.steps / dt / world)},
+                             "survey_8d": survey_8d(last.hits / B, world * B * args.steps / dt / world),
+                             "random_line_roof": line_roof},
                 "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "group": last.group_ms,
                                         "sort_consensus": last.sort_ms, "total": last.total_ms},
                 "per_read_last_step": {"probes": last.probes / B, "postings": last.postings / B,

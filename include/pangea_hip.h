@@ -286,6 +286,11 @@ typedef struct {
 enum { PGX_TRIM_NONE = 0, PGX_TRIM_FASTQ = 1, PGX_TRIM_QSEQ = 2, PGX_TRIM_UNKNOWN = 3 };
 int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fasta_text, size_t *fasta_len, int *mode);
 
+/* diagnostics (tools/probe_gather.py): 64-byte lines per second the device delivers to random 8-byte lane loads over a
+ * table of `table_bytes` — the access shape of the seed stage's index and database fetches, i.e. the roof that stage
+ * can be measured against instead of the streaming bandwidth */
+int pgx_probe_gather(uint64_t table_bytes, int stream, double *lines_per_s, double *ms);
+
 /* instrumentation for bench.py: HIP-event time (ms) of the kernels of the last pipeline call */
 typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;
