@@ -12,6 +12,7 @@
 
 #include "bitops.hpp"
 #include "engine.hpp"
+#include "textops.hpp"
 
 namespace pgx {
 
@@ -108,27 +109,27 @@ __global__ void k_pack_reads(const unsigned char *__restrict__ letters, const ui
 	const uint64_t s = off[r], L = len ? (uint64_t)len[r] : off[r + 1] - s; // `len`: ranges that are not back to back (pieces)
 	const uint32_t w0 = woff[r];
 	uint32_t namb = 0;
-	for (uint64_t w = 0; w * 32 < L; w++) {
-		uint64_t bits = 0, flags = 0;
-		for (int k = 0; k < 32; k++) {
-			const uint64_t i = w * 32 + k;
-			if (i >= L)
-				break;
-			uint32_t c = letter_code(letters[s + i]);
-			if (c >= 4) {
-				namb++;
-				if (fold_to_g)
-					c = 2;
-			}
-			if (c < 4)
-				bits |= (uint64_t)c << (2 * k);
-			else
-				flags |= 1ull << (2 * k);
+	uint64_t bits = 0, flags = 0;
+	// letters come as aligned 16-byte words (textops.hpp): a lane per read walking bytes would fetch every line 64 times
+	for_bytes_at(letters + s, L, [&](uint8_t ch, uint64_t i) {
+		const int k = (int)(i & 31);
+		uint32_t c = letter_code(ch);
+		if (c >= 4) {
+			namb++;
+			if (fold_to_g)
+				c = 2;
 		}
-		fwd[w0 + w] = bits;
-		if (amb)
-			amb[w0 + w] = flags;
-	}
+		if (c < 4)
+			bits |= (uint64_t)c << (2 * k);
+		else
+			flags |= 1ull << (2 * k);
+		if (k == 31 || i + 1 == L) {
+			fwd[w0 + (i >> 5)] = bits;
+			if (amb)
+				amb[w0 + (i >> 5)] = flags;
+			bits = flags = 0;
+		}
+	});
 	if (amb_count)
 		amb_count[r] = namb;
 	if (namb && !fold_to_g)
@@ -861,13 +862,16 @@ __global__ void k_fa_line_info(const unsigned char *__restrict__ text, const uin
 	const bool h = e > s && text[s] == '>';
 	uint32_t c = 0, nl = 0;
 	if (h) {
-		uint32_t k = s + 1;
-		while (k < e && text[k] != ' ' && text[k] != '\t')
-			k++;
-		nl = k - (s + 1);
+		nl = e - (s + 1);
+		bool found = false;
+		for_bytes(text, (uint64_t)s + 1, (uint64_t)(e - (s + 1)), [&](uint8_t b, uint64_t i) {
+			if (!found && (b == ' ' || b == '\t')) {
+				nl = (uint32_t)i;
+				found = true;
+			}
+		});
 	} else {
-		for (uint32_t k = s; k < e; k++)
-			c += text[k] != ' ' && text[k] != '\t';
+		for_bytes(text, (uint64_t)s, (uint64_t)(e - s), [&](uint8_t b, uint64_t) { c += b != ' ' && b != '\t'; });
 	}
 	hdr[l] = h ? 1u : 0u;
 	nlet[l] = c;
@@ -888,25 +892,30 @@ __global__ void k_fa_copy_letters(const unsigned char *__restrict__ text, const 
 				  const uint32_t *__restrict__ name_len, uint32_t n_lines, unsigned char *__restrict__ letters,
 				  uint32_t *__restrict__ rec_let_off, uint32_t *__restrict__ rec_name_off, uint32_t *__restrict__ rec_name_len)
 {
-	const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+	// one group of kGroup lanes per line (textops.hpp): coalesced reads and writes, blanks squeezed out by ballot
+	const uint32_t l = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup);
 	if (l >= n_lines)
 		return;
 	const uint32_t s = line_start[l];
 	if (hdr[l]) {
-		const uint32_t r = rec_incl[l] - 1;
-		rec_let_off[r] = let_off[l];
-		rec_name_off[r] = s + 1;
-		rec_name_len[r] = name_len[l];
+		if ((threadIdx.x & (kGroup - 1)) == 0) {
+			const uint32_t r = rec_incl[l] - 1;
+			rec_let_off[r] = let_off[l];
+			rec_name_off[r] = s + 1;
+			rec_name_len[r] = name_len[l];
+		}
 		return;
 	}
-	uint32_t left = nlet[l], o = let_off[l];
-	for (uint32_t k = s; left; k++) {
-		const unsigned char c = text[k];
-		if (c != ' ' && c != '\t') {
-			letters[o++] = c;
-			left--;
-		}
-	}
+	if (nlet[l] == 0)
+		return; // an empty line, or a line in front of the first record
+	uint32_t e = line_start[l + 1];
+	if (e > s && text[e - 1] == '\n')
+		e--;
+	if (e > s && text[e - 1] == '\r')
+		e--;
+	uint64_t pos = let_off[l];
+	w_copy(reinterpret_cast<char *>(letters), pos, text + s, (uint64_t)(e - s), [](uint8_t c) { return c != ' ' && c != '\t'; },
+	       [](uint8_t c) { return c; });
 }
 
 struct DeviceFasta {
@@ -936,11 +945,11 @@ static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out
 	const uint32_t n = (uint32_t)n_bytes;
 	out.let_off.assign(1, 0);
 	if (n == 0)
-		return out.d_letters.alloc(1);
+		return out.d_letters.alloc(1, 0, 16);
 	DevBuf<unsigned char> d_text;
 	DevBuf<uint8_t> d_flag;
 	DevBuf<uint32_t> d_idx;
-	PGX_TRY(d_text.alloc(n));
+	PGX_TRY(d_text.alloc(n, 0, 16)); // + padding: the kernels read aligned 16-byte words
 	PGX_TRY(d_text.upload((const unsigned char *)text, n));
 	PGX_TRY(d_flag.alloc(n));
 	PGX_TRY(d_idx.alloc(n));
@@ -983,8 +992,8 @@ static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out
 	PGX_TRY(d_rlo.alloc((size_t)n_rec + 1));
 	PGX_TRY(d_rno.alloc((size_t)n_rec + 1));
 	PGX_TRY(d_rnl.alloc((size_t)n_rec + 1));
-	PGX_TRY(out.d_letters.alloc(n_let ? n_let : 1));
-	hipLaunchKernelGGL(k_fa_copy_letters, dim3(gl), dim3(256), 0, 0, d_text.data(), d_line_start.data(), d_hdr.data(), d_nlet.data(),
+	PGX_TRY(out.d_letters.alloc(n_let ? n_let : 1, 0, 16));
+	hipLaunchKernelGGL(k_fa_copy_letters, dim3((unsigned)(((uint64_t)n_lines * kGroup + 255) / 256)), dim3(256), 0, 0, d_text.data(), d_line_start.data(), d_hdr.data(), d_nlet.data(),
 			   d_let_off.data(), d_rec_incl.data(), d_name_len.data(), n_lines, out.d_letters.data(), d_rlo.data(), d_rno.data(),
 			   d_rnl.data());
 	PGX_HIP(hipGetLastError());
@@ -1011,12 +1020,7 @@ constexpr uint32_t kSplitRun = 6, kMinPiece = 28;
 template <typename F> __device__ __forceinline__ void for_pieces(const unsigned char *__restrict__ letters, uint64_t s, uint64_t L, F f)
 {
 	uint64_t st = 0, run = 0; // st: start of the current stretch; run: unknown letters seen just before position i
-	for (uint64_t i = 0; i <= L; i++) {
-		const bool unknown = i < L && letter_code(letters[s + i]) >= 4;
-		if (unknown) {
-			run++;
-			continue;
-		}
+	auto known_at = [&](uint64_t i) { // a known letter, or the end of the read, at position i
 		if (run >= kSplitRun) { // the stretch ended where the run began
 			const uint64_t en = i - run;
 			if (en - st >= kMinPiece)
@@ -1024,9 +1028,16 @@ template <typename F> __device__ __forceinline__ void for_pieces(const unsigned 
 			st = i;
 		}
 		run = 0;
-		if (i == L && L - st >= kMinPiece && st < L)
-			f(st, L - st);
-	}
+	};
+	for_bytes_at(letters + s, L, [&](uint8_t c, uint64_t i) {
+		if (letter_code(c) >= 4)
+			run++;
+		else
+			known_at(i);
+	});
+	known_at(L);
+	if (L - st >= kMinPiece && st < L)
+		f(st, L - st);
 }
 
 // pieces per read; reads with fewer than kSplitRun unknown letters are one piece without a look at their letters
@@ -1255,7 +1266,7 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 		rd->h_text = text_ptr; // names are read from the text on demand
 	} else {
 		rd->h_text = std::make_shared<const std::string>(std::move(own_names));
-		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1);
+		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1, 0, 16);
 		if (rc == 0) rc = d_letters_host.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
 		d_letters_ptr = d_letters_host.data();
 	}
