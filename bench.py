@@ -97,6 +97,24 @@ def main():
     ap.add_argument("--n-seq", type=int, default=666667)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (nor imported torch), so it
+        # may start the ranks itself -- as a CHILD process whose output and exit status it relays (the `mpirun -np N` of
+        # Scripts/submit_MPI-blast.job:24 for this build); never an exec after GPU initialisation
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world_env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,18 +151,32 @@ def main():
         if rank == 0:
             db = pg.Db.from_synth(cfg)
         t_index = time.time() - t0
-        t_bcast = 0.0
+        t_bcast, bcast_bytes, t_rebuild = 0.0, 0, 0.0
         if world > 1:
             from pangea_plus_amd import sharding
             torch.cuda.synchronize()
             t0 = time.time()
-            db = sharding.broadcast_database(
-                db if rank == 0 else None, rank, world, dist, pg.Db.alloc_like,
-                # zero-copy aliases of library-owned HBM
-                lambda d: [(n, torch.as_tensor(v, device=dev)) for n, v in d.device_arrays()],
-                lambda d: d.finish_import())
+            sent = []
+
+            def arrays_of(d):  # zero-copy aliases of library-owned HBM
+                out = [(n, torch.as_tensor(v, device=dev)) for n, v in d.device_arrays()]
+                sent.extend(t.numel() for _, t in out)
+                return out
+
+            t_fin = [0.0]
+
+            def finish(d):  # the receiving ranks build block tables + seed index from the packed bases they were sent
+                torch.cuda.synchronize()
+                t1 = time.time()
+                d.finish_import()
+                t_fin[0] = time.time() - t1
+            db = sharding.broadcast_database(db if rank == 0 else None, rank, world, dist, pg.Db.alloc_like, arrays_of, finish)
             torch.cuda.synchronize()
-            t_bcast = time.time() - t0
+            t_bcast = time.time() - t0 - t_fin[0]
+            bcast_bytes = int(sum(sent))
+            tt = torch.tensor([t_bcast, t_fin[0]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_bcast, t_rebuild = float(tt[0].item()), float(tt[1].item())
         db.bind_taxonomy(tax)
         from pangea_plus_amd.sharding import batch_first_read as sharding_first
         B = args.reads
@@ -234,7 +266,9 @@ def main():
                                         "sort_consensus": last.sort_ms, "total": last.total_ms},
                 "per_read_last_step": {"probes": last.probes / B, "postings": last.postings / B,
                                        "filter_survivors": last.survivors / B, "seed_runs": last.candidates / B, "hits": last.hits / B},
-                "setup_s": {"db_generate_and_index": t_index, "index_broadcast": t_bcast},
+                "setup_s": {"db_generate_and_index": t_index, "index_broadcast": t_bcast, "index_broadcast_bytes": bcast_bytes,
+                            "index_rebuild_on_receivers": t_rebuild if world > 1 else 0.0,
+                            "broadcast_mode": "whole index" if os.environ.get("PGX_BCAST_INDEX", "0") not in ("", "0") else "packed bases + offsets, index rebuilt per GPU"},
             }
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, tmp, args.cpu_sample)

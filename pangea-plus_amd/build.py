@@ -20,6 +20,8 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libpangea_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+if os.environ.get("PGX_STAGE_PROBES"):  # measurement builds only: kernels that can be truncated after a stage
+    FLAGS.append("-DPGX_STAGE_PROBES")
 
 
 def hipcc():

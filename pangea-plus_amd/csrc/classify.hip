@@ -25,6 +25,16 @@
 
 namespace pgx {
 
+// Stage probes (PGX_SEED_STOP / PGX_SORT_STOP truncate the kernels after a stage: tools/probe_stages.py) exist only in
+// builds made with -DPGX_STAGE_PROBES; the shipped kernels carry no such branches.
+#ifdef PGX_STAGE_PROBES
+#define PGX_DBG_STOP(v) ((v).dbg_stop)
+#define PGX_SORT_DBG(v) ((v).dbg)
+#else
+#define PGX_DBG_STOP(v) 0
+#define PGX_SORT_DBG(v) 0
+#endif
+
 struct DbView {
 	const uint64_t *words, *amb;
 	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
@@ -443,7 +453,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	D.hi = hi64 < L ? (int)hi64 : L;
 	Mask M;
 	M.build(D);
-	if (db.dbg_stop == 4) {
+	if (PGX_DBG_STOP(db) == 4) {
 		n_runs += (unsigned long long)(M.first_ge(qp) & 1);
 		return;
 	}
@@ -463,7 +473,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		if (run_start >= D.hi)
 			return; // no exact run of 28 on this diagonal (the dealing-stage filter only bounds it)
 		n_runs++;
-		if (db.dbg_stop == 5 || db.dbg_stop == 6)
+		if (PGX_DBG_STOP(db) == 5 || PGX_DBG_STOP(db) == 6)
 			return;
 	} else {
 		// (1) only the left-most probe inside an exact run reports that run
@@ -478,7 +488,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		if (re - run_start < kWord)
 			return;
 		n_runs++; // a >= 28 exact run reached through its left-most probe
-		if (db.dbg_stop == 5)
+		if (PGX_DBG_STOP(db) == 5)
 			return;
 		// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
 		if constexpr (Mask::kHasWindows) {
@@ -494,7 +504,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				pos = m1 + 1;
 			}
 		}
-		if (db.dbg_stop == 6)
+		if (PGX_DBG_STOP(db) == 6)
 			return;
 	}
 	// (4) spec S3: seeds left to right, X-drop extension on the mismatch flags
@@ -563,7 +573,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				h.sstart = (int32_t)sr;
 				h.send = (int32_t)sl;
 			}
-			if (db.dbg_stop != 7)
+			if (PGX_DBG_STOP(db) != 7)
 				emit(h);
 			covered = br + 1;
 		}
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 		auto drain = [&](unsigned int cnt) {
 			// the last `cnt` queue entries, one per lane
 			q_n -= cnt;
-			if ((unsigned)lane < cnt && db.dbg_stop != 3) {
+			if ((unsigned)lane < cnt && PGX_DBG_STOP(db) != 3) {
 				const uint32_t p = st->qp[q_n + lane], meta = st->qmeta[q_n + lane];
 				const uint32_t sj = st->qsubj[q_n + lane], s0 = st->qs0[q_n + lane], s1 = st->qs1[q_n + lane];
 				const int strand = (int)(meta >> 31), rs = (int)((meta >> 29) & 1), qp = (int)(meta & 0x0FFFFFFFu);
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 			const uint32_t pbase_idx = lo - excl;                               // posting index of item k of this probe: pbase_idx + k
 			const uint32_t pmeta = (uint32_t)qpos | (flank_amb << 28) | ((uint32_t)strand << 31); // what an item needs to know of its probe
 			n_post += cnt;
-			if (db.dbg_stop == 1)
+			if (PGX_DBG_STOP(db) == 1)
 				continue;
 			for (uint32_t it = 0; it < T; it += 64 * kDeal) {
 				// kDeal postings per lane, every load of a stage issued before the first use
@@ -890,7 +900,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 						}
 					}
 				}
-				if (db.dbg_stop == 2) {
+				if (PGX_DBG_STOP(db) == 2) {
 					for (int u = 0; u < kDeal; u++)
 						n_runs += keep[u] + s1[u];
 					continue;
@@ -1278,7 +1288,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 				rcode[b] = 0xFFFFFFFEu;
 		}
 		lds_fence();
-		if (cv.dbg == 1) {
+		if (PGX_SORT_DBG(cv) == 1) {
 			if (mine)
 				hits[o + li] = h;
 			continue;
@@ -1301,7 +1311,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		const SortKey kx = make_key(h, best);
 		lds_fence();
-		if (cv.dbg == 2) {
+		if (PGX_SORT_DBG(cv) == 2) {
 			if (mine) {
 				h.score = best;
 				hits[o + li] = h;
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		if (mine)
 			store_hit_stream(hits + o + rank, h);
-		if (!do_consensus || cv.dbg == 3)
+		if (!do_consensus || PGX_SORT_DBG(cv) == 3)
 			continue;
 		uint32_t rmv = 0, ntok = 0, sim = 0;
 		if (mine) {
@@ -1366,7 +1376,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		for (int m = 1; m < G; m <<= 1)
 			kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
 		const bool elig = mine && k32 == kmax;
-		if (cv.dbg != 4) {
+		if (PGX_SORT_DBG(cv) != 4) {
 			const uint32_t key2 = elig ? ((sim << 6) | (63u - rank)) + 1u : 0u;
 			uint32_t top = key2;
 #pragma unroll

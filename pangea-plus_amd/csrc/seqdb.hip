@@ -538,10 +538,9 @@ int db_build_blk_info(pgx_db *db)
 	return 0;
 }
 
-static int db_upload_offsets(pgx_db *db)
+// block tables derived from d_seq_off (subject of every 512-base block, then the 16-byte block records)
+static int db_build_blocks(pgx_db *db)
 {
-	PGX_TRY(db->d_seq_off.alloc((size_t)db->n_seq + 1));
-	PGX_TRY(db->d_seq_off.upload(db->h_seq_off.data(), (size_t)db->n_seq + 1));
 	uint64_t n_blk = ((uint64_t)db->n_bases >> kBlkShift) + 2;
 	PGX_TRY(db->d_blk_subj.alloc(n_blk));
 	if (db->n_seq > 0) {
@@ -550,6 +549,13 @@ static int db_upload_offsets(pgx_db *db)
 		PGX_HIP(hipGetLastError());
 	}
 	return db_build_blk_info(db);
+}
+
+static int db_upload_offsets(pgx_db *db)
+{
+	PGX_TRY(db->d_seq_off.alloc((size_t)db->n_seq + 1));
+	PGX_TRY(db->d_seq_off.upload(db->h_seq_off.data(), (size_t)db->n_seq + 1));
+	return db_build_blocks(db);
 }
 
 int db_upload_and_index(pgx_db *db)
@@ -1600,6 +1606,15 @@ int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out)
 	return 0;
 }
 
+// What a receiving rank gets over RCCL: by default only the primary data (packed bases, ambiguity flags, sequence
+// offsets: 0.25 GB at 1 Gbp); block tables and the seed index (33 GB) are rebuilt locally by pgx_db_finish_import in
+// the time a broadcast of them would take one xGMI hop.  PGX_BCAST_INDEX=1 ships the built index instead (measurement).
+static bool bcast_whole_index()
+{
+	const char *e = getenv("PGX_BCAST_INDEX");
+	return e && atoi(e) != 0;
+}
+
 int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
 {
 	if (!db || !out)
@@ -1617,10 +1632,12 @@ int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
 	if (db->has_amb)
 		add("amb", db->d_amb.data(), db->d_amb.bytes());
 	add("seq_off", db->d_seq_off.data(), db->d_seq_off.bytes());
-	add("blk_subj", db->d_blk_subj.data(), db->d_blk_subj.bytes());
-	add("bucket_off", db->d_bucket_off.data(), db->d_bucket_off.bytes());
-	add("postings", db->d_postings.data(), db->d_postings.bytes());
-	add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
+	if (bcast_whole_index()) {
+		add("blk_subj", db->d_blk_subj.data(), db->d_blk_subj.bytes());
+		add("bucket_off", db->d_bucket_off.data(), db->d_bucket_off.bytes());
+		add("postings", db->d_postings.data(), db->d_postings.bytes());
+		add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
+	}
 	return n;
 }
 
@@ -1642,14 +1659,16 @@ int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)
 		rc = db->d_amb.alloc(nw, 24, 24, true);
 	if (rc == 0)
 		rc = db->d_seq_off.alloc((size_t)db->n_seq + 1);
-	if (rc == 0)
-		rc = db->d_blk_subj.alloc(((size_t)db->n_bases >> kBlkShift) + 2);
-	if (rc == 0)
-		rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
-	if (rc == 0)
-		rc = db->d_postings.alloc(db->n_postings ? (size_t)db->n_postings : 1);
-	if (rc == 0)
-		rc = db->d_post_ctx.alloc(db->n_postings ? (size_t)db->n_postings : 1);
+	if (bcast_whole_index()) {
+		if (rc == 0)
+			rc = db->d_blk_subj.alloc(((size_t)db->n_bases >> kBlkShift) + 2);
+		if (rc == 0)
+			rc = db->d_bucket_off.alloc((1ull << db->index_bits) + 1);
+		if (rc == 0)
+			rc = db->d_postings.alloc(db->n_postings ? (size_t)db->n_postings : 1);
+		if (rc == 0)
+			rc = db->d_post_ctx.alloc(db->n_postings ? (size_t)db->n_postings : 1);
+	}
 	if (rc < 0) {
 		delete db;
 		return rc;
@@ -1664,7 +1683,14 @@ int pgx_db_finish_import(pgx_db *db)
 		return fail(PGX_E_ARG, "pgx_db_finish_import: null argument");
 	db->h_seq_off.resize((size_t)db->n_seq + 1);
 	PGX_TRY(db->d_seq_off.download(db->h_seq_off.data(), (size_t)db->n_seq + 1));
-	PGX_TRY(db_build_blk_info(db)); // derived table: rebuilt locally, not part of the broadcast
+	if (db->h_seq_off[(size_t)db->n_seq] != (uint32_t)db->n_bases)
+		return fail(PGX_E_FORMAT, "imported sequence offsets do not end at the database length");
+	if (db->d_bucket_off.base) {
+		PGX_TRY(db_build_blk_info(db)); // the index came with the broadcast: only the derived block records are made here
+	} else {
+		PGX_TRY(db_build_blocks(db));
+		PGX_TRY(db_build_index(db));
+	}
 	if (db->synthetic_ids)
 		pgx::synth_ids(db);
 	else if (db->ids.empty())

@@ -1,0 +1,52 @@
+"""GPU, N > 1: the real multi-rank path on the one GPU of the test box.  RCCL does not accept two ranks on one
+device, so the two ranks talk over gloo; everything else is what an 8-GPU run does: `Db.alloc_like` /
+`device_arrays` / `finish_import` on the receiving rank, read blocks per rank, outputs concatenated in rank order."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(kw)
+    return env
+
+
+@pytest.mark.parametrize("whole_index", ["0", "1"])
+def test_two_ranks_import_the_database_and_agree_with_one_rank(tmp_path, whole_index):
+    out = tmp_path / "table.tsv"
+    port = 29700 + os.getpid() % 200 + int(whole_index)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "two_rank_search.py"), str(out), "3001"]
+    p = subprocess.run(cmd, env=_env(PGX_BCAST_INDEX=whole_index), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    status = open(str(out) + ".status").read()
+    assert status.startswith("ok"), status
+    # every read of both blocks is in the table, in file order
+    names = [l.split(b"\t", 1)[0] for l in open(out, "rb").read().splitlines()]
+    firsts = [int(n[1:]) for n in names]
+    assert firsts == sorted(firsts) and firsts[-1] > 2900 and firsts[0] < 5
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no outer launcher: the parent starts the ranks as a child torch.distributed.run
+    and relays the one JSON line, which must say n_gpus 2 (both ranks on device 0 over gloo here)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200000",
+           "--n-seq", "20000", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=_env(PGX_BENCH_ONE_DEVICE="1", PGX_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
+    assert j["setup_s"]["index_broadcast_bytes"] > 0
+    assert j["setup_s"]["broadcast_mode"].startswith("packed bases")

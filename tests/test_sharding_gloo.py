@@ -78,3 +78,29 @@ def test_block_range_matches_cli_partition():
             cuts = [sharding.block_range(total, r, world) for r in range(world)]
             assert cuts[0][0] == 0 and cuts[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N must run N ranks or fail: never N = 1 silently (checked before anything touches a GPU)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_parent_starts_the_ranks_as_a_child_process(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent must start torch.distributed.run as a child (a stub
+    interpreter records the command line here: no GPU in this container)."""
+    import subprocess
+    stub = tmp_path / "python"
+    stub.write_text("#!/bin/sh\necho \"$@\" > %s/argv.txt\nexit 7\n" % tmp_path)
+    stub.chmod(0o755)
+    code = ("import sys, runpy; sys.executable = %r; sys.argv = ['bench.py', '--gpus', '2', '--steps', '3']; "
+            "runpy.run_path(%r, run_name='__main__')" % (str(stub), os.path.join(ROOT, "bench.py")))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 7, p.stderr  # the child's exit status is relayed
+    argv = (tmp_path / "argv.txt").read_text().split()
+    assert argv[:2] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "2" and argv[-4:] == ["--gpus", "2", "--steps", "3"]
