@@ -88,7 +88,8 @@ int o_bench_chain_files(const o_synth_cfg *cfg, int64_t first, int64_t n_reads, 
 	res->hits = (int64_t)hv.n;
 
 	t0 = now_s();
-	o_blast_stats st = { 1.28, 0.46, 0.85, db.total, db.nseq };
+	o_blast_stats st;
+	o_blast_stats_init(&st, db.total, db.nseq, o_blast_gapped);
 	obuf hits_txt;
 	obuf_init(&hits_txt);
 	int nt = threads > 0 ? threads : 1;

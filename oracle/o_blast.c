@@ -39,7 +39,7 @@ static inline int is_match(const uint8_t *q, const uint8_t *s, int64_t d, int32_
 }
 
 void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
-		       void (*emit)(void *, int32_t, int32_t, int32_t, int32_t), void *ctx)
+		       void (*emit)(void *, int32_t, int32_t, int32_t, int32_t, int32_t), void *ctx)
 {
 	int32_t lo = d < 0 ? (int32_t)(-d) : 0;
 	int32_t hi = (int64_t)qlen < (int64_t)slen - d ? qlen : (int32_t)((int64_t)slen - d);
@@ -80,7 +80,7 @@ void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t
 			int32_t mism = 0;
 			for (int32_t k = bl; k <= br; k++)
 				mism += !is_match(q, s, d, k);
-			emit(ctx, bl, br, (j - i) + best + bestr, mism);
+			emit(ctx, bl, br, (j - i) + best + bestr, mism, i);
 			covered = br + 1;
 		}
 		i = j;
@@ -88,10 +88,26 @@ void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t
 }
 
 /* ---------------- statistics (S4) ---------------- */
+int o_blast_gapped = 1, o_blast_prune = 1;
+
+void o_blast_stats_init(o_blast_stats *st, int64_t db_len, int64_t db_nseq, int gapped)
+{
+	/* Karlin-Altschul parameters of blastn for reward 1 / penalty -2: lambda 1.28, K 0.46, H 0.85 with or without
+	 * (linear) gaps; the length adjustment uses alpha 1.5, beta -2 for the gapped search and alpha = lambda / H,
+	 * beta 0 for the ungapped one (the published blastn parameter table) */
+	st->lambda = 1.28;
+	st->K = 0.46;
+	st->H = 0.85;
+	st->db_len = db_len;
+	st->db_nseq = db_nseq;
+	st->alpha = gapped ? 1.5 : st->lambda / st->H;
+	st->beta = gapped ? -2.0 : 0.0;
+}
+
 int64_t o_blast_length_adjust(const o_blast_stats *st, int64_t qlen)
 {
 	/* the published BLAST_ComputeLengthAdjustment iteration; ungapped blastn: alpha/lambda = 1/H, beta = 0 */
-	const double K = st->K, logK = log(st->K), adl = 1.0 / st->H, beta = 0.0;
+	const double K = st->K, logK = log(st->K), adl = st->alpha / st->lambda, beta = st->beta;
 	double m = (double)qlen, n = (double)st->db_len, N = (double)st->db_nseq;
 	double ell, ss, ell_min = 0, ell_max, ell_next = 0;
 	int converged = 0;
@@ -192,9 +208,9 @@ void o_blast_format_hit(const o_hit *h, const o_seqset *queries, const o_seqset 
 	int64_t qlen = queries->off[h->query + 1] - queries->off[h->query];
 	o_blast_format_evalue(o_blast_evalue(st, qlen, h->score), ev);
 	o_blast_format_bitscore(o_blast_bitscore(st, h->score), bs);
-	double pident = 100.0 * (double)(h->length - h->mismatch) / (double)h->length;
-	obuf_printf(out, "%s\t%s\t%.2f\t%d\t%d\t0\t%d\t%d\t%d\t%d\t%s\t%s\n", qid, sid, pident, h->length, h->mismatch,
-		    h->qstart, h->qend, h->sstart, h->send, ev, bs);
+	double pident = 100.0 * (double)(h->length - h->mismatch - h->gaps) / (double)h->length;
+	obuf_printf(out, "%s\t%s\t%.2f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\n", qid, sid, pident, h->length, h->mismatch,
+		    h->gapopen, h->qstart, h->qend, h->sstart, h->send, ev, bs);
 }
 
 /* ---------------- search ---------------- */
@@ -217,11 +233,14 @@ static void hv_push(o_hitvec *v, const o_hit *h)
 
 typedef struct {
 	o_hitvec *out;
-	int32_t query, subject, strand, qlen;
+	int32_t query, subject, strand, qlen, slen;
 	int64_t d;
+	const uint8_t *q, *s; /* the query strand and the subject as base arrays */
 } emit_ctx;
 
-static void emit_hit(void *vctx, int32_t bl, int32_t br, int32_t score, int32_t mism)
+/* S3b: every initial HSP is extended with gaps from the first base of its seed run, to the left and to the right
+ * (o_gapped.c); without the gapped stage (`-ungapped`, spec v1) the initial HSP is the hit */
+static void emit_hit(void *vctx, int32_t bl, int32_t br, int32_t score, int32_t mism, int32_t seed)
 {
 	emit_ctx *c = (emit_ctx *)vctx;
 	o_hit h;
@@ -229,17 +248,33 @@ static void emit_hit(void *vctx, int32_t bl, int32_t br, int32_t score, int32_t 
 	h.subject = c->subject;
 	h.score = score;
 	h.mismatch = mism;
-	h.length = br - bl + 1;
+	h.gapopen = h.gaps = 0;
+	int32_t sl = (int32_t)(bl + c->d), sr = (int32_t)(br + c->d); /* 0-based subject extent */
+	if (o_blast_gapped) {
+		const int32_t qa = seed, sa = (int32_t)(seed + c->d);
+		o_gext L, R;
+		o_greedy_extend(c->q + qa - 1, qa, c->s + sa - 1, sa, -1, o_blast_prune, &L);
+		o_greedy_extend(c->q + qa, c->qlen - qa, c->s + sa, c->slen - sa, +1, o_blast_prune, &R);
+		bl = qa - L.i;
+		br = qa + R.i - 1;
+		sl = sa - L.j;
+		sr = sa + R.j - 1;
+		h.score = (L.s2 + R.s2) >> 1; /* floor of the half-integral score */
+		h.mismatch = L.mism + R.mism;
+		h.gapopen = L.gapopen + R.gapopen;
+		h.gaps = L.gap_s + L.gap_q + R.gap_s + R.gap_q;
+	}
+	h.length = ((br - bl + 1) + (sr - sl + 1) + h.gaps) / 2;
 	if (!c->strand) {
 		h.qstart = bl + 1;
 		h.qend = br + 1;
-		h.sstart = (int32_t)(bl + c->d + 1);
-		h.send = (int32_t)(br + c->d + 1);
+		h.sstart = sl + 1;
+		h.send = sr + 1;
 	} else {
 		h.qstart = c->qlen - br;
 		h.qend = c->qlen - bl;
-		h.sstart = (int32_t)(br + c->d + 1);
-		h.send = (int32_t)(bl + c->d + 1);
+		h.sstart = sr + 1;
+		h.send = sl + 1;
 	}
 	hv_push(c->out, &h);
 }
@@ -275,6 +310,8 @@ static int cmp_final(const void *a, const void *b)
 	CMP(h.qend, 0)
 	CMP(h.sstart, 0)
 	CMP(h.send, 0)
+	CMP(h.mismatch, 0)
+	CMP(h.gapopen, 0)
 #undef CMP
 	return 0;
 }
@@ -401,14 +438,15 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 				}
 				if (!first)
 					continue;
-				emit_ctx c = { &tv[tid], qi, (int32_t)subj, st, qlen, d };
+				emit_ctx c = { &tv[tid], qi, (int32_t)subj, st, qlen, slen, d, q, s };
 				o_blast_diag_hsps(q, qlen, s, slen, d, emit_hit, &c);
 			}
 		}
 	}
 
 	/* merge, E-value filter, order (S4, S5) */
-	o_blast_stats stt = { 1.28, 0.46, 0.85, db->total, db->nseq };
+	o_blast_stats stt;
+	o_blast_stats_init(&stt, db->total, db->nseq, o_blast_gapped);
 	size_t total = 0;
 	for (int t = 0; t < threads; t++)
 		total += tv[t].n;
@@ -441,6 +479,39 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 		i = j;
 	}
 	qsort(hk, n, sizeof(hit_key), cmp_final);
+	/* S3c: hits of one (query, subject) that describe the same alignment.  A hit is dropped when a hit BEFORE it in
+	 * the S5 order (dropped itself or not), on the same strand, starts at the same point, ends at the same point, or
+	 * holds it (query range and subject range) -- the seeds of one alignment on either side of a gap all grow into it */
+	if (o_blast_gapped) {
+		size_t w = 0;
+		uint8_t *drop = (uint8_t *)calloc(n + 1, 1);
+		for (size_t i = 0; i < n;) {
+			size_t j = i;
+			while (j < n && hk[j].h.query == hk[i].h.query && hk[j].h.subject == hk[i].h.subject)
+				j++;
+			for (size_t a = i + 1; a < j; a++) {
+				const o_hit *A = &hk[a].h;
+				const int am = A->sstart > A->send;
+				const int32_t as0 = am ? A->send : A->sstart, as1 = am ? A->sstart : A->send;
+				for (size_t b = i; b < a && !drop[a]; b++) {
+					const o_hit *B = &hk[b].h;
+					const int bm = B->sstart > B->send;
+					if (am != bm)
+						continue;
+					const int32_t bs0 = bm ? B->send : B->sstart, bs1 = bm ? B->sstart : B->send;
+					if ((A->qstart == B->qstart && A->sstart == B->sstart) || (A->qend == B->qend && A->send == B->send) ||
+					    (A->qstart >= B->qstart && A->qend <= B->qend && as0 >= bs0 && as1 <= bs1))
+						drop[a] = 1;
+				}
+			}
+			i = j;
+		}
+		for (size_t i = 0; i < n; i++)
+			if (!drop[i])
+				hk[w++] = hk[i];
+		n = w;
+		free(drop);
+	}
 	int32_t curq = -1, cursubj = -1, nsubj = 0;
 	for (size_t i = 0; i < n; i++) {
 		if (hk[i].h.query != curq) {
@@ -476,7 +547,8 @@ int o_blastn_files(const char *query_fa, const char *db_fa, const char *out_path
 	}
 	o_hitvec hv;
 	o_blast_search(&q, &d, &hv, threads);
-	o_blast_stats st = { 1.28, 0.46, 0.85, d.total, d.nseq };
+	o_blast_stats st;
+	o_blast_stats_init(&st, d.total, d.nseq, o_blast_gapped);
 	obuf out;
 	obuf_init(&out);
 	for (size_t i = 0; i < hv.n; i++)

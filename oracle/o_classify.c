@@ -1,5 +1,5 @@
 /* oracle/ — TEST INFRASTRUCTURE ONLY (see o_common.h). Command-line verbs of the classify stage:
- *   pgx_oracle blastn -query reads.fa -db db.fa -outfmt 6 -out hits.tsv [-num_threads N]   (README.md:96)
+ *   pgx_oracle blastn -query reads.fa -db db.fa -outfmt 6 -out hits.tsv [-num_threads N] [-ungapped] [-no_prune]   (README.md:96)
  *   pgx_oracle soap -a reads.fa -D ref.fa.index -o out.txt [-u unmapped] [-r 0|1|2] [-M 4] [-n 5] [-p N]  (README.md:134)
  *   pgx_oracle synth {db|reads|rdp|taxdump} --out PATH [--n-seq N --seq-len L --n-genus G --first A --count C]
  * The oracle reads the database FASTA directly (no makeblastdb / 2bwt-builder step).
@@ -21,6 +21,12 @@ static int run_blastn(int argc, char **argv)
 	const char *q = arg_of(argc, argv, "-query", NULL), *d = arg_of(argc, argv, "-db", NULL);
 	const char *o = arg_of(argc, argv, "-out", NULL), *f = arg_of(argc, argv, "-outfmt", "6");
 	int nt = atoi(arg_of(argc, argv, "-num_threads", "1"));
+	for (int i = 1; i < argc; i++) {
+		if (strcmp(argv[i], "-ungapped") == 0) /* blastn's own flag: no gapped stage (spec v1) */
+			o_blast_gapped = 0;
+		if (strcmp(argv[i], "-no_prune") == 0) /* the greedy extension without its result-neutral bound cut */
+			o_blast_prune = 0;
+	}
 	if (!q || !d || !o || strcmp(f, "6") != 0) {
 		fprintf(stderr, "usage: blastn -query F -db DB.fa -outfmt 6 -out O\n");
 		return 1;

@@ -59,11 +59,12 @@ int  o_synth_write_db_fasta(const o_synth_cfg *c, const char *path, int64_t firs
 int  o_synth_write_reads_fasta(const o_synth_cfg *c, const char *path, int64_t first, int64_t count);
 int  o_synth_write_rdp(const o_synth_cfg *c, const char *path, int64_t first, int64_t count);
 
-/* ---------- BLAST mode, spec pgx-blastn v1 ---------- */
+/* ---------- BLAST mode, spec pgx-blastn v2 (v1 = its `-ungapped` form) ---------- */
 #define O_BLAST_W 28
 #define O_BLAST_REWARD 1
 #define O_BLAST_PENALTY (-2)
-#define O_BLAST_XDROP 10
+#define O_BLAST_XDROP 10       /* ungapped: floor(20 bits * ln 2 / 1.28) */
+#define O_BLAST_XDROP_GAP 54   /* gapped, final: floor(100 bits * ln 2 / 1.28) */
 #define O_BLAST_MAX_TARGETS 500
 
 typedef struct {
@@ -71,8 +72,9 @@ typedef struct {
 	int32_t subject;  /* subject ordinal */
 	int32_t qstart, qend;   /* 1-based, plus-strand query coordinates, qstart <= qend */
 	int32_t sstart, send;   /* 1-based; sstart > send for minus-strand hits */
-	int32_t score;          /* raw: matches - 2*mismatches */
-	int32_t length, mismatch;
+	int32_t score;          /* raw: floor(matches - 2*mismatches - 2.5*gap columns) */
+	int32_t length, mismatch; /* alignment columns; mismatch columns */
+	int32_t gapopen, gaps;    /* gap openings; gap columns */
 } o_hit;
 
 typedef struct {
@@ -83,11 +85,23 @@ typedef struct {
 typedef struct {
 	double lambda, K, H;
 	int64_t db_len, db_nseq;
+	double alpha, beta; /* length adjustment: gapped 1/-2 linear: 1.5, -2; ungapped: lambda/H, 0 */
 } o_blast_stats;
+void o_blast_stats_init(o_blast_stats *st, int64_t db_len, int64_t db_nseq, int gapped);
+
+/* one side of a gapped extension (o_gapped.c): extent in the query / subject, doubled score, differences */
+typedef struct {
+	int32_t i, j, s2, d;
+	int32_t mism, gap_s, gap_q, gapopen; /* gap_s: query letters facing a gap in the subject row; gap_q: the reverse */
+} o_gext;
+void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, int step, int prune, o_gext *out);
+/* switches of the restatement (defaults 1, 1): gapped = 0 gives `blastn -ungapped` (spec v1); prune = 0 runs the greedy
+ * extension without the result-neutral bound cut */
+extern int o_blast_gapped, o_blast_prune;
 
 /* all HSPs of one diagonal (spec 4.x): q/s are base arrays, d = s_pos - q_pos */
 void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
-		       void (*emit)(void *ctx, int32_t qlo, int32_t qhi, int32_t score, int32_t mism), void *ctx);
+		       void (*emit)(void *ctx, int32_t qlo, int32_t qhi, int32_t score, int32_t mism, int32_t seed), void *ctx);
 /* search every query (both strands) against db; hits come back in the spec's output order */
 int  o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, int threads);
 int64_t o_blast_length_adjust(const o_blast_stats *st, int64_t qlen);

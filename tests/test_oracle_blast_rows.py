@@ -58,7 +58,8 @@ def check_rows(bits_text, pident_text):
 
 
 class _Stats(C.Structure):
-    _fields_ = [("lam", C.c_double), ("K", C.c_double), ("H", C.c_double), ("db_len", C.c_int64), ("db_nseq", C.c_int64)]
+    _fields_ = [("lam", C.c_double), ("K", C.c_double), ("H", C.c_double), ("db_len", C.c_int64), ("db_nseq", C.c_int64),
+                ("alpha", C.c_double), ("beta", C.c_double)]
 
 
 def test_oracle_score_columns_match_the_reference_blast_rows(oracle_bin):
@@ -66,7 +67,7 @@ def test_oracle_score_columns_match_the_reference_blast_rows(oracle_bin):
     lib.o_blast_bitscore.restype = C.c_double
     lib.o_blast_bitscore.argtypes = [C.POINTER(_Stats), C.c_int32]
     lib.o_blast_format_bitscore.argtypes = [C.c_double, C.c_char_p]
-    st = _Stats(1.28, 0.46, 0.85, 10 ** 9, 10 ** 6)
+    st = _Stats(1.28, 0.46, 0.85, 10 ** 9, 10 ** 6, 1.5, -2.0)
 
     def bits_text(s):
         buf = C.create_string_buffer(32)

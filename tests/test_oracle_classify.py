@@ -1,6 +1,7 @@
 """Oracle classify stage: SOAP mode against goldens made by the reference's closed soap ELF,
-BLAST mode (spec pgx-blastn v1, parity unpinned) against an independent brute-force
-restatement of the same spec in Python."""
+BLAST mode (spec pgx-blastn v2 and its `-ungapped` form v1, parity unpinned) against an independent
+brute-force restatement of the same spec in Python, and the gapped extension's score against a plain
+dynamic-programming alignment."""
 import os
 import subprocess
 
@@ -90,7 +91,7 @@ def diag_hsps(q, s, d, W=28, X=10):
                 elif bestr - cur > X:
                     break
             mism = sum(1 for k in range(bl, br + 1) if not mm(k))
-            res.append((bl, br, (j - i) + best + bestr, mism))
+            res.append((bl, br, (j - i) + best + bestr, mism, i))
             covered = br + 1
         i = j
     return res
@@ -104,7 +105,7 @@ def brute_force(queries, db):
         for sn, s in db:
             for strand, qq in ((0, q), (1, rcq)):
                 for d in range(-(L - 28), len(s) - 28 + 1):
-                    for bl, br, score, mism in diag_hsps(qq, s, d):
+                    for bl, br, score, mism, _seed in diag_hsps(qq, s, d):
                         if strand == 0:
                             t = (bl + 1, br + 1, bl + d + 1, br + d + 1)
                         else:
@@ -129,7 +130,7 @@ def test_blast_mode_equals_brute_force_of_the_spec(oracle_bin, tmp_path):
     want = brute_force(read_fa(str(rd)), read_fa(str(db)))
     for nt in ("1", "3"):
         rc, so, se = run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out",
-                              str(out), "-num_threads", nt])
+                              str(out), "-num_threads", nt, "-ungapped"])
         assert rc == 0, se
         got = set()
         lines = out.read_text().splitlines()
@@ -147,6 +148,227 @@ def test_blast_mode_equals_brute_force_of_the_spec(oracle_bin, tmp_path):
             assert lines == first  # thread count never changes the bytes
 
 
+# ---------------------------------------------------------------- gapped stage (spec v2, S3b / S3c)
+X_GAP, LAG, NONE = 54, 19, -10 ** 9
+
+
+def greedy(a, b, prune=False):
+    """Zhang, Schwartz, Wagner, Miller (2000), fig. 4, with the rules oracle/o_gapped.c states; a, b are the letters
+    on one side of the anchor, nearest first.  Returns (i, j, doubled score, mismatches, gap openings, gap columns)."""
+    M, N = len(a), len(b)
+    ok = lambda x, y: x in "ACGT" and x == y
+    i = 0
+    while i < M and i < N and ok(a[i], b[i]):
+        i += 1
+    if i == M or i == N:
+        return i, i, 2 * i, 0, 0, 0
+    prev, L, U = {0: i}, 0, 0
+    T, best, moves = [2 * i], (2 * i, 0, 0, i), {}
+    d = 0
+    while d < 1000:
+        d += 1
+        tcmp = T[d - LAG] if d - LAG >= 0 else 0
+        cur = {}
+        for k in range(L - 1, U + 2):
+            v, par = NONE, 0
+            if L <= k <= U and k in prev:
+                v, par = prev[k] + 1, 0
+            if k - 1 >= L and (k - 1) in prev and prev[k - 1] + 1 > v:
+                v, par = prev[k - 1] + 1, 1
+            if k + 1 <= U and (k + 1) in prev and prev[k + 1] > v:
+                v, par = prev[k + 1], 2
+            ii, jj = v, v - k
+            if v == NONE or ii > M or jj > N or jj < 0 or ii + jj - 6 * d < tcmp - 2 * X_GAP:
+                continue
+            if prune and min(2 * M - k, 2 * N + k) - 6 * d <= best[0]:
+                continue
+            i0 = ii
+            while ii < M and jj < N and ok(a[ii], b[jj]):
+                ii, jj = ii + 1, jj + 1
+            cur[k] = ii
+            moves[(d, k)] = (par, ii > i0)
+            if ii + jj - 6 * d > best[0]:
+                best = (ii + jj - 6 * d, d, k, ii)
+        T.append(best[0])
+        if not cur:
+            break
+        prev, L, U = cur, min(cur), max(cur)
+    s2, bd, k, bi = best
+    path = []
+    for dd in range(bd, 0, -1):
+        par, slid = moves[(dd, k)]
+        path.append((par, slid))
+        k = k - 1 if par == 1 else (k + 1 if par == 2 else k)
+    path.reverse()
+    mism = sum(1 for p, _ in path if p == 0)
+    gaps = len(path) - mism
+    opens, last = 0, (0, True)
+    for par, slid in path:
+        if par != 0 and not (par == last[0] and not last[1]):
+            opens += 1
+        last = (par, slid)
+    return bi, bi - best[2], s2, mism, opens, gaps
+
+
+def dp_best(a, b):
+    """Best score of an alignment of a prefix of a with a prefix of b (match 1, mismatch -2, gap column -2.5), doubled."""
+    import numpy as np
+    M, N = len(a), len(b)
+    H = np.full((M + 1, N + 1), -10 ** 9, dtype=np.int64)
+    H[0, :] = -5 * np.arange(N + 1)
+    H[:, 0] = -5 * np.arange(M + 1)
+    bv = np.frombuffer(b.encode(), dtype=np.uint8)
+    for i in range(1, M + 1):
+        sub = np.where((bv == ord(a[i - 1])) & (a[i - 1] in "ACGT"), 2, -4)
+        diag = H[i - 1, :-1] + sub
+        up = H[i - 1, 1:] - 5
+        row = np.maximum(diag, up)
+        # gaps along the row: prefix scan of max(row[j], row[j-1] - 5)
+        cur = H[i, 0]
+        for j in range(1, N + 1):
+            cur = max(row[j - 1], cur - 5)
+            H[i, j] = cur
+    return int(H.max())
+
+
+def mutate(rng, s, subs, indels):
+    s = list(s)
+    for _ in range(subs):
+        p = rng.randrange(len(s))
+        s[p] = rng.choice([c for c in "ACGT" if c != s[p]])
+    for _ in range(indels):
+        p = rng.randrange(1, len(s) - 1)
+        if rng.random() < 0.5:
+            del s[p:p + rng.choice([1, 1, 2, 3])]
+        else:
+            s[p:p] = [rng.choice("ACGT") for _ in range(rng.choice([1, 1, 2, 3]))]
+    return "".join(s)
+
+
+def test_greedy_extension_is_optimal_and_bound_cut_is_neutral(oracle_bin):
+    """The oracle's C greedy extension equals the Python restatement field by field, with and without the bound cut,
+    and its score is the optimum of a plain dynamic-programming alignment (sequences this similar never drop by X)."""
+    import ctypes
+    import random
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(oracle_bin), "..", "liboracle.so"))
+
+    class Ext(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("i", "j", "s2", "d", "mism", "gap_s", "gap_q", "gapopen")]
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    rng = random.Random(11)
+    n_gapped = 0
+    for case in range(160):
+        L = rng.choice([40, 90, 150, 150, 220])
+        a = "".join(rng.choice("ACGT") for _ in range(L))
+        b = mutate(rng, a, rng.randrange(0, 1 + L // 14), rng.randrange(0, 4)) + "".join(rng.choice("ACGT") for _ in range(rng.choice([0, 30])))
+        if case % 9 == 0:
+            a = a[:L // 2] + "N" + a[L // 2 + 1:]
+        if case % 10 == 0:
+            b = b[:len(b) * 2 // 3]   # the subject ends first
+        want = greedy(a, b)
+        assert greedy(a, b, prune=True) == want
+        ab = bytes(code.get(c, 4) for c in a)
+        bb = bytes(code.get(c, 4) for c in b)
+        for prune in (0, 1):
+            e = Ext()
+            lib.o_greedy_extend(ab, len(a), bb, len(b), 1, prune, ctypes.byref(e))
+            assert (e.i, e.j, e.s2, e.mism, e.gapopen, e.gap_s + e.gap_q) == want, (case, prune)
+        # backwards over the reversed arrays: the same extension
+        e = Ext()
+        ra, rb = ab[::-1], bb[::-1]
+        pa = (ctypes.c_char * len(ra)).from_buffer_copy(ra)
+        pb = (ctypes.c_char * len(rb)).from_buffer_copy(rb)
+        lib.o_greedy_extend(ctypes.byref(pa, len(ra) - 1), len(a), ctypes.byref(pb, len(rb) - 1), len(b), -1, 1, ctypes.byref(e))
+        assert (e.i, e.j, e.s2, e.mism, e.gapopen, e.gap_s + e.gap_q) == want, case
+        i, j, s2, mism, opens, gaps = want
+        assert s2 == i + j - 6 * (mism + gaps) and opens <= gaps
+        assert s2 == dp_best(a, b), case
+        n_gapped += gaps > 0
+    assert n_gapped > 60
+
+
+def brute_force_v2(queries, db):
+    """Spec v2: the initial HSPs of v1, each extended with gaps from the first base of its seed run (S3b), then the
+    hits of one (query, subject) that describe one alignment reduced to the first in the S5 order (S3c)."""
+    rows = []
+    for qn, q in queries:
+        Lq = len(q)
+        rcq = "".join(COMP.get(c, "N") for c in reversed(q))
+        for sn, s in db:
+            group = []
+            for strand, qq in ((0, q), (1, rcq)):
+                for d in range(-(Lq - 28), len(s) - 28 + 1):
+                    for _bl, _br, _score, _mism, seed in diag_hsps(qq, s, d):
+                        qa, sa = seed, seed + d
+                        li, lj, ls2, lm, lo, lg = greedy(qq[:qa][::-1], s[:sa][::-1])
+                        ri, rj, rs2, rm, ro, rg = greedy(qq[qa:], s[sa:])
+                        bl, br, sl, sr = qa - li, qa + ri - 1, sa - lj, sa + rj - 1
+                        gaps = lg + rg
+                        length = ((br - bl + 1) + (sr - sl + 1) + gaps) // 2
+                        if strand == 0:
+                            t = (bl + 1, br + 1, sl + 1, sr + 1)
+                        else:
+                            t = (Lq - br, Lq - bl, sr + 1, sl + 1)
+                        group.append(dict(score=(ls2 + rs2) >> 1, q0=t[0], q1=t[1], s0=t[2], s1=t[3], mm=lm + rm,
+                                          go=lo + ro, length=length, gaps=gaps))
+            group.sort(key=lambda h: (-h["score"], h["q0"], h["q1"], h["s0"], h["s1"], h["mm"], h["go"]))
+            for a in range(len(group)):
+                A = group[a]
+                am = A["s0"] > A["s1"]
+                drop = False
+                for B in group[:a]:
+                    if (B["s0"] > B["s1"]) != am:
+                        continue
+                    alo, ahi = min(A["s0"], A["s1"]), max(A["s0"], A["s1"])
+                    blo, bhi = min(B["s0"], B["s1"]), max(B["s0"], B["s1"])
+                    if ((A["q0"], A["s0"]) == (B["q0"], B["s0"]) or (A["q1"], A["s1"]) == (B["q1"], B["s1"])
+                            or (A["q0"] >= B["q0"] and A["q1"] <= B["q1"] and alo >= blo and ahi <= bhi)):
+                        drop = True
+                        break
+                if not drop:
+                    rows.append((qn, sn, "%.2f" % (100.0 * (A["length"] - A["mm"] - A["gaps"]) / A["length"]), A["length"], A["mm"],
+                                 A["go"], A["q0"], A["q1"], A["s0"], A["s1"]))
+    return set(rows), len(rows)
+
+
+def test_blast_mode_v2_equals_brute_force_of_the_spec(oracle_bin, tmp_path):
+    import random
+    db, rd, out = tmp_path / "db.fa", tmp_path / "reads.fa", tmp_path / "hits.tsv"
+    shape = ["--n-seq", "24", "--seq-len", "330", "--n-genus", "3", "--read-len", "150"]
+    assert run_cmd([oracle_bin, "synth", "db", "--out", str(db)] + shape)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "reads", "--out", str(rd), "--count", "16"] + shape)[0] == 0
+    txt = db.read_text().split("\n")
+    txt[1] = txt[1][:100] + "NNNN" + txt[1][104:200].lower() + txt[1][200:]
+    txt[3] = txt[3][:50] + "R" + txt[3][51:]
+    db.write_text("\n".join(txt))
+    # 454-style reads: every other read gets insertions and deletions
+    rng = random.Random(3)
+    r = rd.read_text().split("\n")
+    for k in range(1, len(r), 2):
+        if r[k] and (k // 2) % 2 == 1:
+            r[k] = mutate(rng, r[k], 1, rng.randrange(1, 4))
+    r[1] = r[1][:70] + "N" + r[1][71:]
+    rd.write_text("\n".join(r))
+    want, n_want = brute_force_v2(read_fa(str(rd)), read_fa(str(db)))
+    assert n_want == len(want)
+    outs = []
+    for flags in (["-num_threads", "1"], ["-num_threads", "3"], ["-num_threads", "2", "-no_prune"]):
+        rc, so, se = run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(out)] + flags)
+        assert rc == 0, se
+        lines = out.read_text().splitlines()
+        got = set()
+        for l in lines:
+            f = l.split("\t")
+            assert len(f) == 12
+            got.add((f[0], f[1], f[2], int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[9])))
+        assert len(got) == len(lines)
+        assert got == want
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2]   # neither threads nor the bound cut change a byte
+    assert sum(1 for l in outs[0] if l.split("\t")[5] != "0") > 20   # gapopen > 0 rows exist
+    assert len(want) > 40
+
+
 def test_blast_statistics_and_formatting(oracle_bin, tmp_path):
     # one exact 150-mer against a one-sequence database: S = 150
     import ctypes
@@ -155,16 +377,26 @@ def test_blast_statistics_and_formatting(oracle_bin, tmp_path):
 
     class St(ctypes.Structure):
         _fields_ = [("lam", ctypes.c_double), ("K", ctypes.c_double), ("H", ctypes.c_double),
-                    ("db_len", ctypes.c_int64), ("db_nseq", ctypes.c_int64)]
+                    ("db_len", ctypes.c_int64), ("db_nseq", ctypes.c_int64), ("alpha", ctypes.c_double), ("beta", ctypes.c_double)]
     lib.o_blast_evalue.restype = ctypes.c_double
     lib.o_blast_bitscore.restype = ctypes.c_double
     lib.o_blast_length_adjust.restype = ctypes.c_int64
-    st = St(1.28, 0.46, 0.85, 1000000500, 666667)
+    st = St()
+    lib.o_blast_stats_init(ctypes.byref(st), ctypes.c_int64(1000000500), ctypes.c_int64(666667), 0)
+    assert (st.lam, st.K, st.H, st.beta) == (1.28, 0.46, 0.85, 0.0)
     adj = lib.o_blast_length_adjust(ctypes.byref(st), ctypes.c_int64(150))
-    # fixed point of ell = (ln K + ln((m-ell)(n-N ell))) / H, floor
+    # ungapped: fixed point of ell = (ln K + ln((m-ell)(n-N ell))) / H, floor
     ell = 0.0
     for _ in range(100):
         ell = (math.log(0.46) + math.log((150 - ell) * (1000000500 - 666667 * ell))) / 0.85
+    assert adj == int(ell)
+    # gapped (spec v2): ell = alpha / lambda * (ln K + ln(...)) + beta with alpha 1.5, beta -2
+    lib.o_blast_stats_init(ctypes.byref(st), ctypes.c_int64(1000000500), ctypes.c_int64(666667), 1)
+    assert (st.alpha, st.beta) == (1.5, -2.0)
+    adj = lib.o_blast_length_adjust(ctypes.byref(st), ctypes.c_int64(150))
+    ell = 0.0
+    for _ in range(100):
+        ell = 1.5 / 1.28 * (math.log(0.46) + math.log((150 - ell) * (1000000500 - 666667 * ell))) - 2.0
     assert adj == int(ell)
     bits = lib.o_blast_bitscore(ctypes.byref(st), ctypes.c_int32(150))
     assert abs(bits - (1.28 * 150 - math.log(0.46)) / math.log(2)) < 1e-9
