@@ -82,8 +82,10 @@ int pgx_db_finish_import(pgx_db *db);
 /* ------------------------------------------------------------------------------------------
  * Classify, BLAST verb  —  `blastn -query F -db DB -outfmt 6 -out O` (README.md:96;
  * Scripts/run_multi_blastn.pl:56) and `mpiblastn in.fasta db out.txt N`
- * (Scripts/submit_MPI-blast.job:24).  Semantics: spec "pgx-blastn v1" (DESIGN.md); BLAST+
- * itself is not vendored by the reference, so parity with NCBI's binary is unpinned.
+ * (Scripts/submit_MPI-blast.job:24).  Semantics: spec "pgx-blastn v2" (DESIGN.md): megablast seeds
+ * (28), ungapped X-drop extension, then the greedy gapped extension and the duplicate-alignment
+ * rule; `ungapped` (blastn's own -ungapped flag) stops after the ungapped stage (= spec v1).
+ * BLAST+ itself is not vendored by the reference, so parity with NCBI's binary is unpinned.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
 	const char *query_path; /* -query */
@@ -91,8 +93,11 @@ typedef struct {
 	const char *out_path;   /* -out   */
 	int outfmt;             /* -outfmt, only 6 */
 	int rank, world_size;   /* read sharding: this process handles block `rank` of `world_size` */
+	int ungapped;           /* -ungapped */
 } pgx_blastn_opts;
 int pgx_blastn_run(const pgx_blastn_opts *opts);
+/* the same switch for searches through a database handle (pgx_blast_search, pgx_classify_consensus): per handle */
+int pgx_db_set_ungapped(pgx_db *db, int ungapped);
 
 /* ------------------------------------------------------------------------------------------
  * Classify, SOAP verb  —  `soap -a reads -D ref.index -o out -p 8 -M 4` (README.md:134;
@@ -200,16 +205,28 @@ typedef struct {
 	int32_t read, subject;
 	int32_t qstart, qend; /* 1-based, plus-strand query coordinates */
 	int32_t sstart, send; /* 1-based; sstart > send on the minus strand */
-	int32_t score;        /* raw: matches - 2 * mismatches */
-	int32_t mismatch;
-} pgx_hit; /* alignment length = qend - qstart + 1 */
+	int32_t score;        /* raw: floor(matches - 2 * mismatches - 2.5 * gap columns) */
+	uint16_t mismatch;    /* mismatch columns */
+	uint16_t gapopen;     /* gap openings */
+} pgx_hit; /* 32 bytes.  The other columns follow from these (PGX_HIT_* below): with q = qend - qstart + 1 and
+	    * s = |send - sstart| + 1, differences d = (q + s - 2 * score - ((q + s) & 1)) / 6, gap columns = d - mismatch,
+	    * alignment length = (q + s + gap columns) / 2, identities = length - d */
+#define PGX_HIT_QSPAN(h) ((h).qend - (h).qstart + 1)
+#define PGX_HIT_SSPAN(h) (((h).send > (h).sstart ? (h).send - (h).sstart : (h).sstart - (h).send) + 1)
+#define PGX_HIT_DIFFS(h) ((PGX_HIT_QSPAN(h) + PGX_HIT_SSPAN(h) - 2 * (h).score - ((PGX_HIT_QSPAN(h) + PGX_HIT_SSPAN(h)) & 1)) / 6)
+#define PGX_HIT_GAPS(h) (PGX_HIT_DIFFS(h) - (int32_t)(h).mismatch)
+#define PGX_HIT_LENGTH(h) ((PGX_HIT_QSPAN(h) + PGX_HIT_SSPAN(h) + PGX_HIT_GAPS(h)) / 2)
 
-typedef struct pgx_hits pgx_hits; /* device hit table of one batch, in -outfmt 6 order */
+/* Device hit table of one batch.  Read r owns the slots [offset[r], offset[r + 1]); its rows, in -outfmt 6 order, are the
+ * first count[r] of them.  The slots behind them hold what the spec removes AFTER the search: hits that describe the
+ * same alignment as an earlier one (spec v2, S3c) and subjects beyond the 500th (S5); no text ever shows them. */
+typedef struct pgx_hits pgx_hits;
 int pgx_blast_search(pgx_db *db, pgx_reads *reads, pgx_hits **out);
 void pgx_hits_close(pgx_hits *h);
-int64_t pgx_hits_count(const pgx_hits *h);
+int64_t pgx_hits_count(const pgx_hits *h); /* slots */
 int pgx_hits_copy(const pgx_hits *h, pgx_hit *out, int64_t cap);           /* device -> host */
-int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap);   /* n_reads+1 offsets */
+int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap);   /* n_reads+1 slot offsets */
+int pgx_hits_read_counts(const pgx_hits *h, int64_t *out, int64_t cap);    /* n_reads row counts */
 /* -outfmt 6 text of the table, malloc'd (pgx_free) */
 int pgx_hits_format(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, char **text, size_t *len);
 
@@ -296,6 +313,8 @@ typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;
 	int64_t probes, postings, candidates, hits;
 	int64_t survivors; /* postings that pass the duplicate filter and get a diagonal mask built */
+	float gapped_ms;     /* spec v2: the gapped stage between seed_extend and group */
+	int64_t gapped_wide; /* HSPs the one-wavefront-per-HSP kernel extended */
 } pgx_stage_times;
 int pgx_last_stage_times(pgx_stage_times *out);
 

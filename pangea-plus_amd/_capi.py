@@ -54,7 +54,8 @@ class SynthCfg(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [("seed_extend_ms", C.c_float), ("group_ms", C.c_float), ("sort_ms", C.c_float),
                 ("consensus_ms", C.c_float), ("total_ms", C.c_float), ("probes", C.c_int64), ("postings", C.c_int64),
-                ("candidates", C.c_int64), ("hits", C.c_int64), ("survivors", C.c_int64)]
+                ("candidates", C.c_int64), ("hits", C.c_int64), ("survivors", C.c_int64), ("gapped_ms", C.c_float),
+                ("gapped_wide", C.c_int64)]
 
 
 class _DevArray(C.Structure):
@@ -68,7 +69,7 @@ class _DbShape(C.Structure):
 
 class _BlastnOpts(C.Structure):
     _fields_ = [("query_path", C.c_char_p), ("db_prefix", C.c_char_p), ("out_path", C.c_char_p), ("outfmt", C.c_int),
-                ("rank", C.c_int), ("world_size", C.c_int)]
+                ("rank", C.c_int), ("world_size", C.c_int), ("ungapped", C.c_int)]
 
 
 class _SoapOpts(C.Structure):
@@ -78,20 +79,20 @@ class _SoapOpts(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("read", "<i4"), ("subject", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"),
-                      ("send", "<i4"), ("score", "<i4"), ("mismatch", "<i4")])
+                      ("send", "<i4"), ("score", "<i4"), ("mismatch", "<u2"), ("gapopen", "<u2")])
 REC_DTYPE = np.dtype([("hit", "<i4"), ("matches", "<i4")])
 
 # every symbol include/pangea_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_db_build", "pgx_db_open",
     "pgx_db_from_fasta", "pgx_db_close", "pgx_db_num_seqs", "pgx_db_num_bases", "pgx_db_seq_id",
-    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run",
+    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped",
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
     "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
-    "pgx_hits_read_offsets", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
+    "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus",
     "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather",
 ]
@@ -112,6 +113,7 @@ def _declare(L):
     sig("pgx_db_num_bases", I64, [V])
     sig("pgx_db_seq_id", S, [V, I64])
     sig("pgx_db_subject_lineage", S, [V, I64])
+    sig("pgx_db_set_ungapped", C.c_int, [V, C.c_int])
     sig("pgx_reads_count", I64, [V])
     sig("pgx_hits_count", I64, [V])
     sig("pgx_reads_from_synth", C.c_int, [V, I64, I64, V])
@@ -120,6 +122,7 @@ def _declare(L):
     sig("pgx_reads_get", C.c_int, [V, I64, V, I32, V])
     sig("pgx_hits_copy", C.c_int, [V, V, I64])
     sig("pgx_hits_read_offsets", C.c_int, [V, V, I64])
+    sig("pgx_hits_read_counts", C.c_int, [V, V, I64])
     sig("pgx_rdp_from_synth", C.c_int, [V, I64, I64, V, V])
     sig("pgx_consensus_batch", C.c_int, [V, V, V, V, I64])
     sig("pgx_classify_consensus", C.c_int, [V, V, V, V, V, I64])
@@ -255,6 +258,10 @@ class Db(_Handle):
         n = _check(lib().pgx_db_device_arrays(self.ptr, arr, 16))
         return [(arr[i].name.decode(), _CudaArray(arr[i].ptr, arr[i].bytes, self)) for i in range(n)]
 
+    def set_ungapped(self, flag=True):
+        """`blastn -ungapped` for searches through this handle: stop after the ungapped stage (spec v1)."""
+        _check(lib().pgx_db_set_ungapped(self.ptr, 1 if flag else 0))
+
     def bind_taxonomy(self, tax):
         _check(lib().pgx_db_bind_taxonomy(self.ptr, tax.ptr))
 
@@ -312,6 +319,17 @@ class Hits(_Handle):
         out = np.zeros(n_reads + 1, dtype=np.int64)
         _check(lib().pgx_hits_read_offsets(self.ptr, out.ctypes.data, n_reads + 1))
         return out
+
+    def read_counts(self, n_reads):
+        out = np.zeros(n_reads, dtype=np.int64)
+        _check(lib().pgx_hits_read_counts(self.ptr, out.ctypes.data, n_reads))
+        return out
+
+    def rows(self, n_reads):
+        """(slots, slot offsets, row mask): the rows a text would show are slots[mask] (see pgx_hits in the header)."""
+        h, off, cnt = self.to_numpy(), self.read_offsets(n_reads), self.read_counts(n_reads)
+        idx = np.arange(len(h)) - np.repeat(off[:-1], np.diff(off))
+        return h, off, idx < np.repeat(cnt, np.diff(off))
 
     def format(self, db, reads):
         txt, ln = C.c_void_p(), C.c_size_t()
@@ -429,9 +447,9 @@ def makeblastdb(infile, out):
     _check(lib().pgx_db_build(_b(infile), _b(out)))
 
 
-def blastn(query, db, out, outfmt=6, rank=0, world_size=1):
-    """`blastn -query F -db DB -outfmt 6 -out O` (reference README.md:96)."""
-    o = _BlastnOpts(_b(query), _b(db), _b(out), int(outfmt), rank, world_size)
+def blastn(query, db, out, outfmt=6, rank=0, world_size=1, ungapped=False):
+    """`blastn -query F -db DB -outfmt 6 -out O [-ungapped]` (reference README.md:96)."""
+    o = _BlastnOpts(_b(query), _b(db), _b(out), int(outfmt), rank, world_size, 1 if ungapped else 0)
     _check(lib().pgx_blastn_run(C.byref(o)))
 
 

@@ -8,7 +8,10 @@
 
 int main(int argc, char **argv)
 {
-	pgx_blastn_opts o = { nullptr, nullptr, nullptr, 6, 0, 1 };
+	pgx_blastn_opts o = { nullptr, nullptr, nullptr, 6, 0, 1, 0 };
+	for (int i = 1; i < argc; i++)
+		if (!strcmp(argv[i], "-ungapped")) // blastn's own flag: ungapped alignments only (spec v1)
+			o.ungapped = 1;
 	for (int i = 1; i + 1 < argc; i++) {
 		if (!strcmp(argv[i], "-query")) o.query_path = argv[++i];
 		else if (!strcmp(argv[i], "-db")) o.db_prefix = argv[++i];

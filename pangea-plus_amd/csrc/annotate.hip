@@ -24,7 +24,7 @@ namespace pgx {
 
 bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
 			     std::string &out, int *rc_out);
-void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, Text &out);
+void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, Text &out);
 
 // ------------------------------------------------------------------------------------------ lineage text
 LineageRenderer::~LineageRenderer() { delete cache; }
@@ -859,7 +859,7 @@ int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hit
 			// with the blank in front of a 3-digit bit score eaten by its split (taxcollector:77,148-153)
 			std::string line = reads->name_of(r) + "\t" + db->ids[(size_t)h.subject] + "\t";
 			cols.s.clear();
-			format_hit_columns(h, reads->h_len[(size_t)r], db->n_bases, db->n_seq, cols);
+			format_hit_columns(h, reads->h_len[(size_t)r], db->n_bases, db->n_seq, !db->ungapped, cols);
 			line += cols.s;
 			emit_collected(line, db->lineage[(size_t)h.subject], out.s);
 		} else {

@@ -1,21 +1,26 @@
 // Reads with more hits than one wavefront orders in LDS (> 64), of any size: a conserved 16S region against a 16S
 // collection gives a read tens of thousands of hits, so this path must not be quadratic.
 //
-// Spec S5 order = (best score of the subject desc, subject asc, score desc, qstart, qend, sstart, send).  It is
-// produced by four stable segmented radix sorts (one segment per read), least significant key first:
+// Spec S5 order = (best score of the subject desc, subject asc, score desc, qstart, qend, sstart, send, mismatch,
+// gapopen).  It is produced by five stable segmented radix sorts (one segment per read), least significant key first:
+//     0  send, mismatch, gap openings (gapped hits: send no longer follows from the other columns)
 //     1  sstart, then strand (minus before plus: with equal qstart/qend/sstart that is `send` ascending)
 //     2  qstart, qend
 //     3  subject asc, score desc      -> the head of every subject run holds the subject's best score
 //     4  best score desc
-// then the 500-subject cut (subjects are contiguous in the order) and the write-back into the hit table.
+// After sort 3 the hits of a subject are in the S5 order of their HSPs: spec v2's duplicate-alignment rule S3c is
+// applied there (a dropped hit gets the last place of the read in sort 4); then the 500-subject cut (subjects are
+// contiguous in the order) and the write-back into the hit table.
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <mutex>
 
 #include "engine.hpp"
 
 namespace pgx {
 
-constexpr uint32_t kFragmentedRead = 0xFFFFFFFFu; // read_start value of a read whose hits went through the overflow table
+constexpr uint32_t kFragmentedRead = kFragmented;
 
 __global__ void k_big_lens(const uint32_t *__restrict__ off, const uint32_t *__restrict__ big_list, uint32_t n_big,
 			   uint32_t *__restrict__ len)
@@ -57,7 +62,9 @@ __global__ void k_big_keys(const pgx_hit *__restrict__ work, const uint32_t *__r
 	const uint32_t v = vals[g];
 	const pgx_hit h = work[v];
 	unsigned long long k;
-	if (PASS == 1)
+	if (PASS == 0)
+		k = ((unsigned long long)(uint32_t)h.send << 32) | ((unsigned long long)h.mismatch << 16) | (unsigned long long)h.gapopen;
+	else if (PASS == 1)
 		k = ((unsigned long long)(uint32_t)h.sstart << 1) | (h.send > h.sstart ? 1ull : 0ull);
 	else if (PASS == 2)
 		k = ((unsigned long long)(uint32_t)h.qstart << 32) | (unsigned long long)(uint32_t)h.qend;
@@ -85,19 +92,54 @@ __global__ __launch_bounds__(256) void k_big_best(const pgx_hit *__restrict__ wo
 	}
 }
 
+// Spec v2, S3c inside one subject run (hits in S5 order): a hit is dropped when an EARLIER hit of the run, on the same
+// strand, starts at the same point, ends at the same point, or holds it.  Dropped hits sort behind every kept one.
+__global__ __launch_bounds__(256) void k_big_dedup(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
+						    const uint32_t *__restrict__ seg_off, uint32_t n_big, uint32_t *__restrict__ best,
+						    uint32_t *__restrict__ seg_drop)
+{
+	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
+		const uint32_t g0 = seg_off[k], g1 = seg_off[k + 1];
+		for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+			const uint32_t v = vals[g];
+			const pgx_hit a = work[v];
+			const bool am = a.sstart > a.send;
+			const int as0 = am ? a.send : a.sstart, as1 = am ? a.sstart : a.send;
+			bool drop = false;
+			for (uint32_t h = g; h > g0 && !drop;) {
+				h--;
+				const pgx_hit b = work[vals[h]];
+				if (b.subject != a.subject)
+					break;
+				const bool bm = b.sstart > b.send;
+				if (bm != am)
+					continue;
+				const int bs0 = bm ? b.send : b.sstart, bs1 = bm ? b.sstart : b.send;
+				drop = (a.qstart == b.qstart && a.sstart == b.sstart) || (a.qend == b.qend && a.send == b.send) ||
+				       (a.qstart >= b.qstart && a.qend <= b.qend && as0 >= bs0 && as1 <= bs1);
+			}
+			if (drop) {
+				best[v] = 0u; // sort 4 places it behind the kept hits of the read
+				atomicAdd(&seg_drop[k], 1u);
+			}
+		}
+	}
+}
+
 // final order back into the hit table; read_cnt = hits kept by the 500-subject limit (spec S5)
 __global__ __launch_bounds__(256) void k_big_write(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
 						    const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ off,
 						    const uint32_t *__restrict__ big_list, uint32_t n_big, pgx_hit *__restrict__ hits,
-						    uint32_t *__restrict__ read_cnt)
+						    uint32_t *__restrict__ read_cnt, const uint32_t *__restrict__ seg_drop)
 {
 	__shared__ uint32_t s_warp[4];
 	__shared__ uint32_t s_carry, s_keep;
 	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
 		const uint32_t r = big_list[k], o = off[r], g0 = seg_off[k], n = seg_off[k + 1] - g0;
+		const uint32_t n_kept = n - seg_drop[k]; // the dropped hits (S3c) are the last ones of the segment
 		if (threadIdx.x == 0) {
 			s_carry = 0;
-			s_keep = n;
+			s_keep = n_kept;
 		}
 		__syncthreads();
 		for (uint32_t base = 0; base < n; base += blockDim.x) {
@@ -107,7 +149,7 @@ __global__ __launch_bounds__(256) void k_big_write(const pgx_hit *__restrict__ w
 			if (j < n) {
 				h = work[vals[g0 + j]];
 				hits[o + j] = h;
-				flag = j == 0 || work[vals[g0 + j - 1]].subject != h.subject;
+				flag = j < n_kept && (j == 0 || work[vals[g0 + j - 1]].subject != h.subject);
 			}
 			// running count of distinct subjects up to and including position j
 			const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -135,17 +177,42 @@ __global__ __launch_bounds__(256) void k_big_write(const pgx_hit *__restrict__ w
 
 // hits: the ordered hit table (big reads' slots are rewritten); scratch/read_start: the seed kernel's table
 int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_start, const uint32_t *off, uint32_t *read_cnt,
-		   const uint32_t *big_list, uint32_t n_big)
+		   const uint32_t *big_list, uint32_t n_big, bool gapped)
 {
 	if (n_big == 0)
 		return 0;
+	// the work tables below are shared by every handle of the process: one caller at a time (a rare path)
+	static std::mutex mu;
+	std::lock_guard<std::mutex> lock(mu);
 	// work tables live across calls (grow-only): a batch with a handful of big reads would otherwise pay a dozen
 	// hipMalloc / hipFree pairs (≈ 1.3 ms) for a few microseconds of sorting
-	static DevBuf<uint32_t> seg, va, vb, best;
-	static DevBuf<pgx_hit> work;
-	static DevBuf<unsigned long long> ka, kb;
-	static DevBuf<uint8_t> scan_tmp, sort_tmp;
+	// (never freed: a static destructor would call hipFree after the runtime may be gone; released and re-made when the
+	// process moves to another device)
+	struct BigWork {
+		DevBuf<uint32_t> seg, va, vb, best, seg_drop;
+		DevBuf<pgx_hit> work;
+		DevBuf<unsigned long long> ka, kb;
+		DevBuf<uint8_t> scan_tmp, sort_tmp;
+		int device = -1;
+	};
+	static BigWork *bw = nullptr;
+	int dev = 0;
+	PGX_HIP(hipGetDevice(&dev));
+	if (bw && bw->device != dev) {
+		delete bw; // tables of another device
+		bw = nullptr;
+	}
+	if (!bw) {
+		bw = new BigWork();
+		bw->device = dev;
+	}
+	DevBuf<uint32_t> &seg = bw->seg, &va = bw->va, &vb = bw->vb, &best = bw->best, &seg_drop = bw->seg_drop;
+	DevBuf<pgx_hit> &work = bw->work;
+	DevBuf<unsigned long long> &ka = bw->ka, &kb = bw->kb;
+	DevBuf<uint8_t> &scan_tmp = bw->scan_tmp, &sort_tmp = bw->sort_tmp;
 	PGX_TRY(seg.ensure((size_t)n_big + 1));
+	PGX_TRY(seg_drop.ensure((size_t)n_big + 1));
+	PGX_HIP(hipMemsetAsync(seg_drop.data(), 0, ((size_t)n_big + 1) * sizeof(uint32_t), 0));
 	hipLaunchKernelGGL(k_big_lens, dim3((n_big + 1 + 255) / 256), dim3(256), 0, 0, off, big_list, n_big, seg.data());
 	PGX_HIP(hipGetLastError());
 	{
@@ -181,6 +248,8 @@ int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_s
 		std::swap(cur, nxt);
 		return 0;
 	};
+	hipLaunchKernelGGL(k_big_keys<0>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
+	PGX_TRY(sort_pass(64));
 	hipLaunchKernelGGL(k_big_keys<1>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
 	PGX_TRY(sort_pass(33));
 	hipLaunchKernelGGL(k_big_keys<2>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
@@ -188,9 +257,11 @@ int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_s
 	hipLaunchKernelGGL(k_big_keys<3>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
 	PGX_TRY(sort_pass(64));
 	hipLaunchKernelGGL(k_big_best, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), n_big, best.data());
+	if (gapped)
+		hipLaunchKernelGGL(k_big_dedup, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), n_big, best.data(), seg_drop.data());
 	hipLaunchKernelGGL(k_big_keys<4>, dim3(el_grid), dim3(256), 0, 0, work.data(), cur, best.data(), total, ka.data());
 	PGX_TRY(sort_pass(32));
-	hipLaunchKernelGGL(k_big_write, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), off, big_list, n_big, hits, read_cnt);
+	hipLaunchKernelGGL(k_big_write, dim3(seg_grid), dim3(256), 0, 0, work.data(), cur, seg.data(), off, big_list, n_big, hits, read_cnt, seg_drop.data());
 	PGX_HIP(hipGetLastError());
 	return 0;
 }

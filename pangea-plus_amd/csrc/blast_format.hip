@@ -12,15 +12,25 @@
 namespace pgx {
 
 struct BlastStats {
-	double lambda = 1.28, K = 0.46, H = 0.85; // ungapped blastn, reward 1 / penalty -2
+	// blastn, reward 1 / penalty -2: lambda 1.28, K 0.46, H 0.85 with or without (linear) gaps; the length adjustment
+	// uses alpha 1.5, beta -2 for the gapped search (spec v2) and alpha = lambda / H, beta 0 for `-ungapped` (the
+	// published blastn parameter table)
+	double lambda = 1.28, K = 0.46, H = 0.85, alpha = 1.5, beta = -2.0;
 	int64_t db_len = 0, db_nseq = 0;
+	void set(int64_t len, int64_t nseq, bool gapped)
+	{
+		db_len = len;
+		db_nseq = nseq;
+		alpha = gapped ? 1.5 : lambda / H;
+		beta = gapped ? -2.0 : 0.0;
+	}
 };
 
-// BLAST's length adjustment: largest ell with ell <= (ln K + ln((m-ell)(n-N ell)))/H, found by the
-// published bracketing iteration (20 rounds at most)
+// BLAST's length adjustment: largest ell with ell <= alpha / lambda * (ln K + ln((m-ell)(n-N ell))) + beta, found by
+// the published bracketing iteration (20 rounds at most)
 static int64_t length_adjust(const BlastStats &st, int64_t qlen)
 {
-	const double logK = std::log(st.K), adl = 1.0 / st.H;
+	const double logK = std::log(st.K), adl = st.alpha / st.lambda, beta = st.beta;
 	const double m = (double)qlen, n = (double)st.db_len, N = (double)st.db_nseq;
 	const double c = n * m - std::max(m, n) / st.K;
 	if (c < 0)
@@ -30,7 +40,7 @@ static int64_t length_adjust(const BlastStats &st, int64_t qlen)
 	bool converged = false;
 	for (int i = 1; i <= 20; i++) {
 		const double ell = ell_next;
-		const double ell_bar = adl * (logK + std::log((m - ell) * (n - N * ell)));
+		const double ell_bar = adl * (logK + std::log((m - ell) * (n - N * ell))) + beta;
 		if (ell_bar >= ell) {
 			ell_min = ell;
 			if (ell_bar - ell_min <= 1.0) {
@@ -50,7 +60,7 @@ static int64_t length_adjust(const BlastStats &st, int64_t qlen)
 	int64_t adj = (int64_t)ell_min;
 	if (converged) {
 		const double up = std::ceil(ell_min);
-		if (up <= ell_max && adl * (logK + std::log((m - up) * (n - N * up))) >= up)
+		if (up <= ell_max && adl * (logK + std::log((m - up) * (n - N * up))) + beta >= up)
 			adj = (int64_t)up;
 	}
 	return adj;
@@ -100,36 +110,36 @@ static void format_bitscore(double b, char out[32])
 }
 
 // the 10 numeric columns of one hit ("pident\tlength\t...\tbitscore"), shared with the consensus text
-void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, Text &out)
+void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, Text &out)
 {
 	BlastStats st;
-	st.db_len = db_len;
-	st.db_nseq = db_nseq;
+	st.set(db_len, db_nseq, gapped);
 	static thread_local int64_t cached_qlen = -1, cached_len = -1, cached_nseq = -1;
+	static thread_local int cached_gapped = -1;
 	static thread_local double cached_sp = 0;
-	if (cached_qlen != qlen || cached_len != db_len || cached_nseq != db_nseq) {
+	if (cached_qlen != qlen || cached_len != db_len || cached_nseq != db_nseq || cached_gapped != (int)gapped) {
 		cached_sp = search_space(st, qlen);
 		cached_qlen = qlen;
 		cached_len = db_len;
 		cached_nseq = db_nseq;
+		cached_gapped = (int)gapped;
 	}
-	const int length = h.qend - h.qstart + 1;
+	const int length = hit_length(h), diffs = hit_diffs(h);
 	const double evalue = cached_sp * std::exp(-st.lambda * (double)h.score + std::log(st.K));
 	const double bits = (st.lambda * (double)h.score - std::log(st.K)) / std::log(2.0);
 	char ev[32], bs[32];
 	format_evalue(evalue, ev);
 	format_bitscore(bits, bs);
-	const double pident = 100.0 * (double)(length - h.mismatch) / (double)length;
-	out.printf("%.2f\t%d\t%d\t0\t%d\t%d\t%d\t%d\t%s\t%s", pident, length, h.mismatch, h.qstart, h.qend, h.sstart,
-		   h.send, ev, bs);
+	const double pident = 100.0 * (double)(length - diffs) / (double)length;
+	out.printf("%.2f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s", pident, length, (int)h.mismatch, (int)h.gapopen, h.qstart, h.qend,
+		   h.sstart, h.send, ev, bs);
 }
 
 // the e-value and bit-score columns of a hit of raw score `score` for a query of `qlen` bases
-void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_nseq, std::string &evalue, std::string &bits)
+void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, std::string &evalue, std::string &bits)
 {
 	BlastStats st;
-	st.db_len = db_len;
-	st.db_nseq = db_nseq;
+	st.set(db_len, db_nseq, gapped);
 	const double sp = search_space(st, qlen);
 	const double e = sp * std::exp(-st.lambda * (double)score + std::log(st.K));
 	const double b = (st.lambda * (double)score - std::log(st.K)) / std::log(2.0);
@@ -150,7 +160,7 @@ extern "C" int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_l
 	if (!evalue || !bits || qlen <= 0 || db_len <= 0 || db_nseq <= 0)
 		return pgx::fail(PGX_E_ARG, "pgx_blast_score_columns: bad argument");
 	std::string e, b;
-	pgx::format_score_columns(score, qlen, db_len, db_nseq, e, b);
+	pgx::format_score_columns(score, qlen, db_len, db_nseq, true, e, b);
 	snprintf(evalue, 32, "%s", e.c_str());
 	snprintf(bits, 32, "%s", b.c_str());
 	return 0;
@@ -176,7 +186,7 @@ static int format_hits_text_host(const pgx_hits *h, const pgx_db *db, const pgx_
 			out.s += '\t';
 			out.s += db->ids[(size_t)x.subject];
 			out.s += '\t';
-			format_hit_columns(x, qlen, db->n_bases, db->n_seq, out);
+			format_hit_columns(x, qlen, db->n_bases, db->n_seq, !db->ungapped, out);
 			out.s += '\n';
 		}
 	}
@@ -245,8 +255,8 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 	}
 	if (WRITE && !valid)
 		return;
-	const int alen = h.qend - h.qstart + 1;
-	const int hund = pident_hundredths(alen - h.mismatch, alen);
+	const int alen = hit_length(h);
+	const int hund = pident_hundredths(alen - hit_diffs(h), alen);
 	const uint32_t qlen = v.read_len[r];
 	const uint32_t e = v.slot_base[v.len_slot[qlen]] + (uint32_t)h.score;
 	const uint32_t so = v.score_off[e], sn = v.score_off[e + 1] - so;
@@ -260,7 +270,7 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 	}
 	if (!WRITE) {
 		len_or_off[j - j0] = (unsigned long long)nn + in + (dec_len((unsigned long long)(hund / 100)) + 3) + dec_len((unsigned long long)alen) +
-				     dec_len((unsigned long long)h.mismatch) + 1 + dec_len((unsigned long long)h.qstart) +
+				     dec_len((unsigned long long)h.mismatch) + dec_len((unsigned long long)h.gapopen) + dec_len((unsigned long long)h.qstart) +
 				     dec_len((unsigned long long)h.qend) + dec_len((unsigned long long)h.sstart) +
 				     dec_len((unsigned long long)h.send) + sn + 10 /* tabs (the 11th is inside the score text) */ + 1 /* newline */;
 		return;
@@ -284,7 +294,7 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 	*p++ = '\t';
 	p = put_dec(p, (unsigned long long)h.mismatch);
 	*p++ = '\t';
-	*p++ = '0';
+	p = put_dec(p, (unsigned long long)h.gapopen);
 	*p++ = '\t';
 	p = put_dec(p, (unsigned long long)h.qstart);
 	*p++ = '\t';
@@ -432,8 +442,8 @@ __global__ void k_fmt_consensus(ConsFmtView c, uint64_t r0, uint64_t r1, unsigne
 	uint32_t so = 0, sn = 0, io = 0, in = 0, no = 0, nn = 0;
 	if (rec.hit >= 0) {
 		h = v.hits[rec.hit];
-		alen = h.qend - h.qstart + 1;
-		hund = pident_hundredths(alen - h.mismatch, alen);
+		alen = hit_length(h);
+		hund = pident_hundredths(alen - hit_diffs(h), alen);
 		const uint32_t e = v.slot_base[v.len_slot[v.read_len[r]]] + (uint32_t)h.score;
 		so = v.score_off[e];
 		sn = v.score_off[e + 1] - so;
@@ -447,7 +457,7 @@ __global__ void k_fmt_consensus(ConsFmtView c, uint64_t r0, uint64_t r1, unsigne
 			nn = 1 + dec_len(v.first + r);
 		}
 		row = nn + in + (dec_len((unsigned long long)(hund / 100)) + 3) + dec_len((unsigned long long)alen) +
-		      dec_len((unsigned long long)h.mismatch) + 1 + dec_len((unsigned long long)h.qstart) + dec_len((unsigned long long)h.qend) +
+		      dec_len((unsigned long long)h.mismatch) + dec_len((unsigned long long)h.gapopen) + dec_len((unsigned long long)h.qstart) + dec_len((unsigned long long)h.qend) +
 		      dec_len((unsigned long long)h.sstart) + dec_len((unsigned long long)h.send) + sn + 10 + 1;
 	}
 	if (!WRITE) {
@@ -474,7 +484,7 @@ __global__ void k_fmt_consensus(ConsFmtView c, uint64_t r0, uint64_t r1, unsigne
 		*p++ = '\t';
 		p = put_dec(p, (unsigned long long)h.mismatch);
 		*p++ = '\t';
-		*p++ = '0';
+		p = put_dec(p, (unsigned long long)h.gapopen);
 		*p++ = '\t';
 		p = put_dec(p, (unsigned long long)h.qstart);
 		*p++ = '\t';
@@ -517,7 +527,7 @@ static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t 
 		slot_base.push_back((uint32_t)score_off.size());
 		for (uint32_t sc = 0; sc <= L; sc++) {
 			score_off.push_back((uint32_t)score_blob.size());
-			format_score_columns((int)sc, L, db->n_bases, db->n_seq, ev, bs);
+			format_score_columns((int)sc, L, db->n_bases, db->n_seq, !db->ungapped, ev, bs);
 			score_blob += ev;
 			score_blob += '\t';
 			size_t b0 = 0;
@@ -659,6 +669,12 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 	PGX_TRY(require_device());
 	pgx_db *db = nullptr;
 	PGX_TRY(pgx_db_open(o->db_prefix, &db));
+	db->ungapped = o->ungapped != 0;
+	// (a rank outside [0, world_size) used to write an empty file and succeed)
+	if (o->world_size > 0 && (o->rank < 0 || o->rank >= o->world_size)) {
+		pgx_db_close(db);
+		return fail(PGX_E_ARG, "blastn: rank %d is outside [0, %d)", o->rank, o->world_size);
+	}
 	// read sharding (mpiblastn's static query partition, Scripts/submit_MPI-blast.job:24): this
 	// process takes block `rank` of `world_size` contiguous blocks
 	int ws = o->world_size > 0 ? o->world_size : 1, rk = o->rank;

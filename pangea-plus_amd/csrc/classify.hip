@@ -25,34 +25,6 @@
 
 namespace pgx {
 
-// Stage probes (PGX_SEED_STOP / PGX_SORT_STOP truncate the kernels after a stage: tools/probe_stages.py) exist only in
-// builds made with -DPGX_STAGE_PROBES; the shipped kernels carry no such branches.
-#ifdef PGX_STAGE_PROBES
-#define PGX_DBG_STOP(v) ((v).dbg_stop)
-#define PGX_SORT_DBG(v) ((v).dbg)
-#else
-#define PGX_DBG_STOP(v) 0
-#define PGX_SORT_DBG(v) 0
-#endif
-
-struct DbView {
-	const uint64_t *words, *amb;
-	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
-	const uint4 *blk_info;
-	const uint3 *post_ctx;
-	const uint32_t *amb_blk; // one bit per 512-base block with an ambiguity letter (null: the database has none)
-	uint32_t n_seq;
-	int bits;
-	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
-};
-
-struct ReadsView {
-	const uint64_t *fwd, *rc, *fwd_amb, *rc_amb;
-	const uint32_t *len, *woff;
-	uint32_t n;           // reads this launch works on
-	const uint32_t *list; // their ids (null: 0 .. n-1): a batch is searched class by class (flag words, ambiguity)
-};
-
 // ------------------------------------------------------------------------------------------ diagonal masks
 struct Diag {
 	const uint64_t *rw, *ra;   // read words / spaced ambiguity flags of the strand (ra may be null)
@@ -335,7 +307,6 @@ constexpr int kStage = 128; // hits staged in LDS per wave between flushes
 constexpr int kDeal = 2;     // postings dealt per lane per round (independent loads in flight)
 constexpr int kQueue = 64 * (kDeal + 1); // candidate queue per wave (filled 64*kDeal at a time, drained at >= 64)
 constexpr int kWavesPerBlock = 4;
-constexpr uint32_t kFragmented = 0xFFFFFFFFu;
 
 // the ordered hit table is written once and read by a later call: streamed past the caches (the database words,
 // block records and subject records are what should stay in them)
@@ -401,7 +372,8 @@ __device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
 	const int span = h.qend - h.qstart;
 	h.send = (c.z >> 31) ? h.sstart - span : h.sstart + span;
 	h.score = (int32_t)(c.w & 0xFFFFu);
-	h.mismatch = (int32_t)(c.w >> 16);
+	h.mismatch = (uint16_t)(c.w >> 16);
+	h.gapopen = 0;
 	return h;
 }
 
@@ -559,8 +531,11 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 			pgx_hit h;
 			h.read = (int32_t)read;
 			h.subject = (int32_t)s;
-			h.score = len + best + bestr;
-			h.mismatch = mm_best + mmr_best;
+			// spec v2: this is an INITIAL HSP; the gapped stage (gapped.hip) extends it from the first base of its seed
+			// run, whose offset from the HSP's start travels in the score field
+			h.score = db.gapped ? pos - bl : len + best + bestr;
+			h.mismatch = (uint16_t)(db.gapped ? 0 : mm_best + mmr_best);
+			h.gapopen = 0;
 			const int64_t sl = D.dstart + bl - (int64_t)s_start + 1, sr = D.dstart + br - (int64_t)s_start + 1;
 			if (!strand) {
 				h.qstart = bl + 1;
@@ -1076,15 +1051,19 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_final(const uint32_t *__res
 		off[n] = run;
 }
 
-__global__ void k_scatter_hits(const pgx_hit *__restrict__ in, uint64_t n_hits, const uint32_t *__restrict__ off,
-			       uint32_t *__restrict__ cursor, pgx_hit *__restrict__ out)
+// the overflow table's hits into their reads' slots; the count is read on the device (the host does not wait for it)
+__global__ void k_scatter_hits(const pgx_hit *__restrict__ in, const unsigned long long *__restrict__ n_ptr, unsigned long long in_cap,
+			       const uint32_t *__restrict__ off, uint32_t *__restrict__ cursor, pgx_hit *__restrict__ out,
+			       unsigned long long out_cap)
 {
+	const uint64_t n_hits = *n_ptr < in_cap ? *n_ptr : in_cap;
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (; i < n_hits; i += stride) {
 		pgx_hit h = in[i];
 		uint32_t slot = off[h.read] + atomicAdd(&cursor[h.read], 1u);
-		out[slot] = h;
+		if (slot < out_cap)
+			out[slot] = h;
 	}
 }
 
@@ -1107,10 +1086,10 @@ struct ConsView {
 // string-order rank of the hit's pident text
 __device__ __forceinline__ uint32_t hit_simrank(const ConsView &cv, const pgx_hit &h)
 {
-	const int len = h.qend - h.qstart + 1;
+	const int len = hit_length(h), diffs = hit_diffs(h); // columns, columns that are not identities
 	if (len < 256)
-		return cv.simrank_len[len * 256 + h.mismatch];
-	return cv.simrank_lut[pident_hundredths(len - h.mismatch, len)];
+		return cv.simrank_len[len * 256 + diffs];
+	return cv.simrank_lut[pident_hundredths(len - diffs, len)];
 }
 
 constexpr int kRdpRegs = 8; // RDP triplets of a read kept in registers by the fast agreement count
@@ -1170,6 +1149,7 @@ constexpr int kSortCap = 64; // hits of one read ordered by its wave: one hit pe
 // sstart < 2^31 because database positions are.
 struct SortKey {
 	uint64_t k1, k2;
+	uint32_t send, mg; // third level (gapped hits: send no longer follows from the other columns): send, then mismatch, gap openings
 };
 __device__ __forceinline__ SortKey make_key(const pgx_hit &h, int best)
 {
@@ -1177,6 +1157,8 @@ __device__ __forceinline__ SortKey make_key(const pgx_hit &h, int best)
 	k.k1 = ((uint64_t)(0xFFFF - best) << 48) | ((uint64_t)(uint32_t)h.subject << 16) | (uint64_t)(0xFFFF - h.score);
 	k.k2 = ((uint64_t)(uint32_t)h.qstart << 48) | ((uint64_t)(uint32_t)h.qend << 32) |
 	       (uint64_t)(((uint32_t)h.sstart << 1) | (h.send > h.sstart ? 1u : 0u));
+	k.send = (uint32_t)h.send;
+	k.mg = ((uint32_t)h.mismatch << 16) | (uint32_t)h.gapopen;
 	return k;
 }
 
@@ -1188,6 +1170,7 @@ struct SortWave {
 		struct {
 			uint64_t k1[kSortCap], k2[kSortCap];
 			int subj[kSortCap], score[kSortCap];
+			uint32_t send[kSortCap], mg[kSortCap];
 		} a;
 		struct {
 			uint64_t krm[kSortCap], kcnt[kSortCap]; // text-order keys of the agreement and token counts
@@ -1206,7 +1189,8 @@ template <int G>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_hit *__restrict__ hits,
 									 const pgx_hit *__restrict__ scratch,
 									 const uint32_t *__restrict__ read_start,
-									 const uint32_t *__restrict__ off, uint32_t n_reads,
+									 const uint32_t *__restrict__ off, uint32_t *__restrict__ read_cnt,
+									 unsigned long long hits_cap, unsigned long long scratch_cap, uint32_t n_reads,
 									 const uint32_t *__restrict__ list,
 									 const uint32_t *__restrict__ n_list_ptr, ConsView cv,
 									 int do_consensus, int lds_ok,
@@ -1233,6 +1217,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		const uint32_t o = valid ? off[r] : 0u;
 		uint32_t n = valid ? off[r + 1] - o : 0u;
+		if ((unsigned long long)o + n > hits_cap)
+			n = 0; // the table was sized on a guess that was too small: the host grows it and repeats the step
 		if (valid && n == 0 && do_consensus && li == 0) {
 			recs[r].hit = -2;
 			recs[r].matches = 0;
@@ -1264,11 +1250,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		if (pass_on)
 			n = 0; // not ours
 		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
-		const uint32_t st0 = n ? read_start[r] : 0u;
+		uint32_t st0 = n ? read_start[r] : 0u;
+		if (n && st0 != kFragmented && (unsigned long long)st0 + n > scratch_cap) {
+			n = 0; // the seed stage's table was too small: the step is repeated
+			st0 = 0;
+		}
 		const pgx_hit *src = st0 == kFragmented ? hits + o : scratch + st0;
 		const bool mine = (uint32_t)li < n;
 		pgx_hit h;
-		h.subject = h.score = h.qstart = h.qend = h.sstart = h.send = h.mismatch = h.read = 0;
+		h.subject = h.score = h.qstart = h.qend = h.sstart = h.send = h.read = 0;
+		h.mismatch = h.gapopen = 0;
 		if (mine) {
 			h = src[li];
 			sw->a.subj[slot0 + li] = h.subject;
@@ -1297,6 +1288,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		// flight per round; rows past a read's end (stale bytes) are masked by j < n.
 		const uint32_t nmax = RPW == 2 ? max(__shfl(n, 0), __shfl(n, 32)) : n;
 		int best = h.score;
+		uint32_t same_subj = 0; // hits of this read on the hit's subject (itself included)
 		for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
 			int sj[4], sc[4];
 #pragma unroll
@@ -1306,8 +1298,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++)
-				if (j0 + u < n && sj[u] == h.subject && sc[u] > best)
-					best = sc[u];
+				if (j0 + u < n && sj[u] == h.subject) {
+					same_subj++;
+					if (sc[u] > best)
+						best = sc[u];
+				}
 		}
 		const SortKey kx = make_key(h, best);
 		lds_fence();
@@ -1321,8 +1316,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		if (mine) {
 			sw->a.k1[slot0 + li] = kx.k1;
 			sw->a.k2[slot0 + li] = kx.k2;
+			sw->a.send[slot0 + li] = kx.send;
+			sw->a.mg[slot0 + li] = kx.mg;
 		}
 		lds_fence();
+		// Spec v2, S3c: hits of one subject that describe the same alignment (the seeds on either side of a gap all grow
+		// into it).  A hit is dropped when a hit BEFORE it in the S5 order, on the same subject and strand, starts at the
+		// same point, ends at the same point, or holds it.  Only reads with two hits on one subject look (wave-uniform).
+		bool dropped = false;
+		if (__ballot(mine && same_subj > 1u)) {
+			const uint32_t my_s0 = (uint32_t)(h.send > h.sstart ? h.sstart : h.send), my_s1 = (uint32_t)(h.send > h.sstart ? h.send : h.sstart);
+			for (uint32_t j = 0; j < nmax; j++) {
+				const uint32_t sl = slot0 + (j & (G - 1));
+				const uint64_t b1 = sw->a.k1[sl], b2 = sw->a.k2[sl];
+				const uint32_t bsend = sw->a.send[sl], bmg = sw->a.mg[sl];
+				const bool before = (b1 < kx.k1) | ((b1 == kx.k1) & ((b2 < kx.k2) | ((b2 == kx.k2) & ((bsend < kx.send) | ((bsend == kx.send) &
+						    ((bmg < kx.mg) | ((bmg == kx.mg) & (j < (uint32_t)li))))))));
+				const bool same = (uint32_t)(b1 >> 16) == (uint32_t)h.subject && ((b2 ^ kx.k2) & 1ull) == 0ull;
+				const uint32_t bq0 = (uint32_t)(b2 >> 48), bq1 = (uint32_t)(b2 >> 32) & 0xFFFFu, bsst = (uint32_t)(b2 >> 1) & 0x7FFFFFFFu;
+				const uint32_t bs0 = bsend > bsst ? bsst : bsend, bs1 = bsend > bsst ? bsend : bsst;
+				const bool dup = (bq0 == (uint32_t)h.qstart && bsst == (uint32_t)h.sstart) || (bq1 == (uint32_t)h.qend && bsend == (uint32_t)h.send) ||
+						 ((uint32_t)h.qstart >= bq0 && (uint32_t)h.qend <= bq1 && my_s0 >= bs0 && my_s1 <= bs1);
+				dropped |= (j < n) & before & same & dup;
+			}
+		}
+		const unsigned long long drop_mask = __ballot(mine && dropped);
+		const unsigned long long grp_mask = G == 64 ? ~0ull : (g ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+		const uint32_t n_drop = (uint32_t)__popcll(drop_mask & grp_mask);
+		const uint32_t n_all = n; // slots of the read; n becomes the hits that are kept
+		const bool kept = mine && !dropped;
+		if (n_drop) {
+			n -= n_drop;
+			if (li == 0)
+				read_cnt[r] = n;
+		}
 		// rank = number of hits that precede this one.  Nearly every pair differs in the first key word (best
 		// score, subject, score): count on that word alone, and compare second words only inside groups of equal
 		// first words (several HSPs of one subject with one score), which most reads do not have.
@@ -1334,24 +1361,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 				a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
-				const bool in = j0 + u < n;
+				const bool in = (j0 + u < n_all) & !((drop_mask >> (slot0 + ((j0 + u) & (G - 1)))) & 1ull);
 				rank += (in & (a1[u] < kx.k1)) ? 1u : 0u;
 				same += (in & (a1[u] == kx.k1)) ? 1u : 0u;
 			}
 		}
-		if (__ballot(mine && same > 1u)) {
+		if (__ballot(kept && same > 1u)) {
 			for (uint32_t j = 0; j < nmax; j++) {
-				const uint64_t b1 = sw->a.k1[slot0 + (j & (G - 1))], b2 = sw->a.k2[slot0 + (j & (G - 1))];
-				const bool before = (b1 == kx.k1) & ((b2 < kx.k2) | ((b2 == kx.k2) & (j < (uint32_t)li)));
-				rank += (before & (j < n)) ? 1u : 0u;
+				const uint32_t sl = slot0 + (j & (G - 1));
+				const uint64_t b1 = sw->a.k1[sl], b2 = sw->a.k2[sl];
+				const uint32_t bsend = sw->a.send[sl], bmg = sw->a.mg[sl];
+				const bool before = (b1 == kx.k1) & ((b2 < kx.k2) | ((b2 == kx.k2) & ((bsend < kx.send) | ((bsend == kx.send) &
+						    ((bmg < kx.mg) | ((bmg == kx.mg) & (j < (uint32_t)li)))))));
+				rank += (before & (j < n_all) & !((drop_mask >> sl) & 1ull)) ? 1u : 0u;
 			}
 		}
+		if (dropped) // dropped hits keep the slots behind the kept ones (the table stays initialised)
+			rank = n + (uint32_t)__popcll(drop_mask & grp_mask & ((1ull << lane) - 1ull));
 		if (mine)
 			store_hit_stream(hits + o + rank, h);
 		if (!do_consensus || PGX_SORT_DBG(cv) == 3)
 			continue;
 		uint32_t rmv = 0, ntok = 0, sim = 0;
-		if (mine) {
+		if (kept) {
 			rmv = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
 			sim = hit_simrank(cv, h);
 		}
@@ -1360,8 +1392,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		// step maxcount stays c, so the winner is, among the hits whose agreement count is the text-order
 		// maximum, the first one in table order whose pident text is greatest.  That is two reductions
 		// over the read's lanes; anything else takes the literal walk below.
-		const uint32_t c0 = __shfl(ntok, slot0);
-		const bool odd = mine && (ntok != c0 || ntok == 0u || rmv >= 100000000u || sim >= (1u << 25));
+		const unsigned long long kept_mask = __ballot(kept) & grp_mask;
+		const uint32_t c0 = __shfl(ntok, kept_mask ? __ffsll((unsigned long long)kept_mask) - 1 : slot0);
+		const bool odd = kept && (ntok != c0 || ntok == 0u || rmv >= 100000000u || sim >= (1u << 25));
 		const unsigned long long odd_mask = __ballot(odd);
 		const unsigned long long gmask = G == 64 ? ~0ull : (g ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
 		const bool slow = (odd_mask & gmask) != 0ull;
@@ -1370,12 +1403,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			recs[r].hit = -2;
 			recs[r].matches = 0;
 		}
-		const uint32_t k32 = mine ? dec_str_key32(rmv) : 0u; // >= 1 for any value
+		const uint32_t k32 = kept ? dec_str_key32(rmv) : 0u; // >= 1 for any value
 		uint32_t kmax = k32;
 #pragma unroll
 		for (int m = 1; m < G; m <<= 1)
 			kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
-		const bool elig = mine && k32 == kmax;
+		const bool elig = kept && k32 == kmax;
 		if (PGX_SORT_DBG(cv) != 4) {
 			const uint32_t key2 = elig ? ((sim << 6) | (63u - rank)) + 1u : 0u;
 			uint32_t top = key2;
@@ -1388,11 +1421,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 		}
 		if (odd_mask) {
-			const bool any_huge = __ballot(mine && (rmv >= 100000000u || ntok >= 100000000u || sim >= (1u << 25))) != 0ull;
+			const bool any_huge = __ballot(kept && (rmv >= 100000000u || ntok >= 100000000u || sim >= (1u << 25))) != 0ull;
 			lds_fence(); // every lane is done with the keys: the bytes become the per-rank arrays
 			if (any_huge) {
 				// counts of nine digits and more: 64-bit text keys, the literal walk
-				if (mine) {
+				if (kept) {
 					sw->b.rm[slot0 + rank] = rmv;
 					sw->b.sim[slot0 + rank] = sim;
 					sw->b.krm[slot0 + rank] = dec_str_key(rmv);
@@ -1415,7 +1448,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 				// text greater), and after a replacement the remembered token count is j's own.  Every lane finds
 				// the successor of its own hit (one pass over the per-rank arrays), lane 0 follows the chain.
 				const uint32_t c32 = dec_str_key32(ntok);
-				if (mine) {
+				if (kept) {
 					sw->c.kcnt[slot0 + rank] = c32;
 					sw->c.sim_e[slot0 + rank] = sim | (elig ? 0x80000000u : 0u);
 					sw->c.krm[slot0 + rank] = k32;
@@ -1429,10 +1462,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 						uint32_t nx = kNoRead;
 						for (uint32_t t = 0; t < n; t++) {
 							const uint32_t a = sw->c.kcnt[slot0 + t], b2 = sw->c.sim_e[slot0 + t];
-							const bool cand = mine && t > rank && (b2 >> 31) && (a > c32 || (b2 & 0x7FFFFFFFu) > sim);
+							const bool cand = kept && t > rank && (b2 >> 31) && (a > c32 || (b2 & 0x7FFFFFFFu) > sim);
 							nx = (cand && nx == kNoRead) ? t : nx;
 						}
-						if (mine)
+						if (kept)
 							sw->c.nxt[slot0 + rank] = nx;
 						lds_fence();
 						if (li == 0) {
@@ -1519,7 +1552,7 @@ __global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint3
 }
 
 // ------------------------------------------------------------------------------------------ host drivers
-static pgx_stage_times g_times;
+static thread_local pgx_stage_times t_times; // stage times of the calling thread's last pipeline call
 
 static DbView db_view(const pgx_db *db)
 {
@@ -1535,6 +1568,7 @@ static DbView db_view(const pgx_db *db)
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;
 	v.bits = db->index_bits;
+	v.gapped = db->ungapped ? 0 : 1;
 	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0;
 	return v;
 }
@@ -1580,26 +1614,26 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 	return cv;
 }
 
-struct EventTimer {
-	hipEvent_t a = nullptr, b = nullptr;
-	EventTimer()
+// stage boundaries on the pipeline's stream; read only after the one synchronisation at the end of the step
+struct StageEvents {
+	static constexpr int kN = 6;
+	hipEvent_t e[kN] = {};
+	bool ok = false;
+	int init()
 	{
-		(void)hipEventCreate(&a);
-		(void)hipEventCreate(&b);
+		if (ok)
+			return 0;
+		for (auto &x : e)
+			PGX_HIP(hipEventCreate(&x));
+		ok = true;
+		return 0;
 	}
-	~EventTimer()
+	void mark(int i, hipStream_t s) { (void)hipEventRecord(e[i], s); }
+	float ms(int a, int b) const
 	{
-		(void)hipEventDestroy(a);
-		(void)hipEventDestroy(b);
-	}
-	void start() { (void)hipEventRecord(a, 0); }
-	float stop()
-	{
-		(void)hipEventRecord(b, 0);
-		(void)hipEventSynchronize(b);
-		float ms = 0;
-		(void)hipEventElapsedTime(&ms, a, b);
-		return ms;
+		float t = 0;
+		(void)hipEventElapsedTime(&t, e[a], e[b]);
+		return t;
 	}
 };
 
@@ -1610,14 +1644,17 @@ struct EventTimer {
 // hits of every piece are moved there with the read's number and the piece's offset on the query coordinates.
 __global__ __launch_bounds__(256) void k_merge_pieces(const pgx_hit *__restrict__ scratch, const uint32_t *__restrict__ piece_start,
 						      const uint32_t *__restrict__ piece_off, const uint32_t *__restrict__ parent,
-						      const uint32_t *__restrict__ qoff, uint32_t n_pieces, pgx_hit *__restrict__ hits)
+						      const uint32_t *__restrict__ qoff, uint32_t n_pieces, pgx_hit *__restrict__ hits,
+						      unsigned long long hits_cap, unsigned long long scratch_cap)
 {
 	const uint32_t waves = gridDim.x * (blockDim.x / 64), lane = threadIdx.x & 63;
 	for (uint32_t s = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); s < n_pieces; s += waves) {
 		const uint32_t o = piece_off[s], cnt = piece_off[s + 1] - o;
-		if (cnt == 0)
+		if (cnt == 0 || (unsigned long long)o + cnt > hits_cap)
 			continue;
 		const uint32_t st = piece_start[s];
+		if (st != kFragmented && (unsigned long long)st + cnt > scratch_cap)
+			continue;
 		const pgx_hit *src = st == kFragmented ? hits + o : scratch + st; // fragmented pieces were scattered in place
 		const int32_t read = (int32_t)parent[s], shift = (int32_t)qoff[s];
 		for (uint32_t i = lane; i < cnt; i += 64) {
@@ -1644,18 +1681,50 @@ __global__ void k_piece_ranges(const uint32_t *__restrict__ piece_first, const u
 	}
 }
 
+// Everything a search through one database handle needs between and during calls: owned by the handle (pgx_db::work),
+// so two handles searched from two host threads share nothing; searches through ONE handle are serialised by its mutex.
+// The steady state of a batch loop allocates nothing, and the host waits for the device once per step.
 struct Workspace {
-	DevBuf<unsigned long long> counters;
+	hipStream_t stream = nullptr;
+	StageEvents ev;
+	DevBuf<unsigned long long> counters; // [0..7] seed stage (OutView), [8] reads passed to the big-read path, [9] 33..64-hit list
+	unsigned long long *h_counters = nullptr; // pinned mirror of counters + the gapped stage's list count
 	DevBuf<pgx_hit> scratch, ovf;
-	DevBuf<uint32_t> partial, cursor, big_list, big_count, read_start, mid_list, mid_count;
+	DevBuf<uint32_t> partial, cursor, big_list, read_start, mid_list;
 	DevBuf<uint32_t> piece_cnt, piece_off, parent_start; // batches searched piece by piece
 	DevBuf<pgx_consensus_rec> recs;
+	GappedWork gapped;
 	pgx_hits hits; // used when the caller does not keep the hit table
-	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0;
+	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0, table_hint = 0;
+	pgx_stage_times times;
+	int device = -1;
+	~Workspace()
+	{
+		// (the handle is closed by its owner while the runtime is alive; nothing here runs from a static destructor)
+		if (h_counters)
+			(void)hipHostFree(h_counters);
+		if (stream)
+			(void)hipStreamDestroy(stream);
+	}
 };
-static Workspace g_ws;
+constexpr int kNCounters = 12;
 
-// search + group + sort (+ consensus when rdp != null). d_recs: device array of n_reads records.
+static int workspace_of(pgx_db *db, Workspace **out)
+{
+	if (!db->work) {
+		auto w = std::make_shared<Workspace>();
+		PGX_HIP(hipGetDevice(&w->device));
+		PGX_HIP(hipStreamCreate(&w->stream));
+		PGX_HIP(hipHostMalloc((void **)&w->h_counters, (kNCounters + 2) * sizeof(unsigned long long)));
+		PGX_TRY(w->ev.init());
+		PGX_TRY(w->counters.alloc(kNCounters, 0, 0, true));
+		db->work = w;
+	}
+	*out = static_cast<Workspace *>(db->work.get());
+	return 0;
+}
+
+// search + gapped stage + group + order (+ consensus when rdp != null). d_recs: device array of n_reads records.
 int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out, pgx_consensus_rec *d_recs)
 {
 	PGX_TRY(require_device());
@@ -1663,15 +1732,20 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		return fail(PGX_E_ARG, "consensus needs pgx_db_bind_taxonomy() first");
 	if (rdp && rdp->n != rd->n)
 		return fail(PGX_E_ARG, "RDP stream holds %lld reads, batch holds %lld", (long long)rdp->n, (long long)rd->n);
-	memset(&g_times, 0, sizeof g_times);
+	std::lock_guard<std::mutex> lock(db->search_mu);
+	Workspace *wsp = nullptr;
+	PGX_TRY(workspace_of(db, &wsp));
+	Workspace &ws = *wsp;
+	hipStream_t st = ws.stream;
+	pgx_stage_times &tm = ws.times;
+	memset(&tm, 0, sizeof tm);
 	const uint64_t n = (uint64_t)rd->n;
 	out->n_reads = rd->n;
 	PGX_TRY(out->d_read_cnt.ensure(n + 1));
 	PGX_TRY(out->d_read_off.ensure(n + 1));
-	DevBuf<unsigned long long> &counters = g_ws.counters;
-	PGX_TRY(counters.ensure(8));
 	if (n == 0) {
 		out->n_hits = 0;
+		t_times = tm;
 		return 0;
 	}
 	index_check(db, "search_pipeline");
@@ -1681,42 +1755,55 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	const pgx_reads *sr = split ? rd->pieces.get() : rd;
 	const uint64_t ns = (uint64_t)sr->n;
 	if (split) {
-		PGX_TRY(g_ws.piece_cnt.ensure(ns + 1));
-		PGX_TRY(g_ws.piece_off.ensure(ns + 1));
-		PGX_TRY(g_ws.parent_start.ensure(n));
+		PGX_TRY(ws.piece_cnt.ensure(ns + 1));
+		PGX_TRY(ws.piece_off.ensure(ns + 1));
+		PGX_TRY(ws.parent_start.ensure(n));
 	}
 	const ReadsView rv = reads_view(sr);
 	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
-	EventTimer total, t;
-	total.start();
 
-	// seed + extend: unfragmented reads land contiguously in `scratch`, the rest in `ovf`;
-	// grow and repeat if a guess was too small
-	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 40, 1 << 16) + 256ull * 8 * kWavesPerBlock * kChunk, g_ws.hit_cap_hint);
-	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) / 4, 1 << 16), g_ws.ovf_cap_hint);
-	DevBuf<pgx_hit> &scratch = g_ws.scratch, &ovf = g_ws.ovf;
-	DevBuf<uint32_t> &read_start = g_ws.read_start;
+	// capacities are guesses kept from earlier calls; every kernel checks them, the counters say at the end of the
+	// step whether one was too small, and the step is then repeated with larger tables
+	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 40, 1 << 16) + 256ull * 8 * kWavesPerBlock * kChunk, ws.hit_cap_hint);
+	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) / 4, 1 << 16), ws.ovf_cap_hint);
+	uint64_t table_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 36, 1 << 16), ws.table_hint);
+	DevBuf<pgx_hit> &scratch = ws.scratch, &ovf = ws.ovf;
+	DevBuf<uint32_t> &read_start = ws.read_start;
 	PGX_TRY(read_start.ensure(std::max(n, ns)));
-	unsigned long long h_cnt[8];
+	unsigned long long *h_cnt = ws.h_counters;
 	// reads are searched class by class (engine.hpp: pgx_reads::classes); a database with ambiguity letters makes every
 	// class ambiguity-aware
 	const std::vector<pgx_reads::SearchClass> &classes = sr->classes;
-	bool dense = true; // every read keeps its flags in registers (the ordering kernels then see no read longer than 512)
+	bool long_reads = false; // a class whose flags do not fit registers (reads above 512 bases)
 	for (auto &c : classes)
-		dense = dense && c.words > 0;
-	for (;;) {
+		long_reads = long_reads || c.words == 0;
+	const uint32_t n_part = (uint32_t)((ns + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
+	PGX_TRY(ws.partial.ensure(n_part));
+	PGX_TRY(ws.cursor.ensure(ns));
+	PGX_TRY(ws.big_list.ensure(n));
+	PGX_TRY(ws.mid_list.ensure(n + 64ull * kWavesPerBlock * 256 * 8)); // + one open chunk per wave
+	const ConsView cv = cons_view(db, rdp);
+	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
+	uint64_t H = 0, H_ovf = 0;
+	for (int attempt = 0;; attempt++) {
+		if (attempt > 8)
+			return fail(PGX_E_LIMIT, "hit tables did not settle after %d attempts", attempt);
 		PGX_TRY(scratch.ensure(cap));
 		PGX_TRY(ovf.ensure(ovf_cap));
+		PGX_TRY(out->d_hits.ensure(table_cap));
 		cap = scratch.n;
 		ovf_cap = ovf.n;
-		PGX_HIP(hipMemsetAsync(counters.data(), 0, 8 * sizeof(unsigned long long), 0));
+		table_cap = out->d_hits.n;
+		PGX_HIP(hipMemsetAsync(ws.counters.data(), 0, kNCounters * sizeof(unsigned long long), st));
 		OutView ov;
 		ov.main = scratch.data();
 		ov.ovf = ovf.data();
 		ov.main_cap = cap;
 		ov.ovf_cap = ovf_cap;
-		ov.counters = counters.data();
-		t.start();
+		ov.counters = ws.counters.data();
+		uint32_t *big_count = reinterpret_cast<uint32_t *>(ws.counters.data() + 8), *mid_count = reinterpret_cast<uint32_t *>(ws.counters.data() + 9);
+		ws.ev.mark(0, st);
+		uint32_t *rc_ptr = split ? ws.piece_cnt.data() : out->d_read_cnt.data(), *rs_ptr = read_start.data();
 		for (const pgx_reads::SearchClass &c0 : classes) {
 			pgx_reads::SearchClass c = c0;
 			c.amb = c.amb || db->has_amb;
@@ -1726,13 +1813,12 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			cvw.list = c.listed ? sr->d_class_list.data() + c.off : nullptr;
 			const int per_block = kWavesPerBlock * (c.words > 0 ? 2 : 1);
 			const dim3 g((unsigned)std::min<uint64_t>((cn + per_block - 1) / per_block, 256ull * 8)), b(64 * kWavesPerBlock);
-			uint32_t *rc_ptr = split ? g_ws.piece_cnt.data() : out->d_read_cnt.data(), *rs_ptr = read_start.data();
 #define PGX_SEED_LAUNCH(A, W)                                                                                                      \
 	do {                                                                                                                       \
 		if (c.listed)                                                                                                      \
-			hipLaunchKernelGGL((k_seed_extend<A, W, true>), g, b, 0, 0, dv, cvw, ov, rc_ptr, rs_ptr);                 \
+			hipLaunchKernelGGL((k_seed_extend<A, W, true>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);                \
 		else                                                                                                               \
-			hipLaunchKernelGGL((k_seed_extend<A, W, false>), g, b, 0, 0, dv, cvw, ov, rc_ptr, rs_ptr);                \
+			hipLaunchKernelGGL((k_seed_extend<A, W, false>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);               \
 	} while (0)
 			if (c.amb && c.words == 3)
 				PGX_SEED_LAUNCH(true, 3);
@@ -1752,102 +1838,129 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 				PGX_SEED_LAUNCH(false, 0);
 #undef PGX_SEED_LAUNCH
 		}
-		trace_point("k_seed_extend");
 		PGX_HIP(hipGetLastError());
-		g_times.seed_extend_ms = t.stop();
-		PGX_TRY(counters.download(h_cnt, 8));
-		if (h_cnt[0] <= cap && h_cnt[4] <= ovf_cap)
+		trace_point("k_seed_extend");
+		ws.ev.mark(1, st);
+
+		// spec v2: the initial HSPs become gapped alignments, in place (gapped.hip)
+		if (dv.gapped) {
+			ReadsView all = rv;
+			all.n = (uint32_t)ns;
+			PGX_TRY(gapped_stage(dv, all, scratch.data(), rs_ptr, rc_ptr, ovf.data(), ws.counters.data() + 4, ovf_cap, long_reads, cap,
+					     ws.gapped, st));
+			trace_point("gapped_stage");
+		}
+		ws.ev.mark(2, st);
+
+		// group by read: exclusive scan of the per-read counts; only the overflow hits need a scatter
+		// (per piece when the batch was searched piece by piece: the scan of the piece counts is the per-read layout too)
+		const uint32_t *unit_cnt = split ? ws.piece_cnt.data() : out->d_read_cnt.data();
+		uint32_t *unit_off = split ? ws.piece_off.data() : out->d_read_off.data();
+		hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, st, unit_cnt, ns, ws.partial.data());
+		hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, ws.partial.data(), n_part);
+		hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, st, unit_cnt, ns, ws.partial.data(), unit_off);
+		// (overflow hits are rare; their count is only known on the device, so the scatter always runs)
+		PGX_HIP(hipMemsetAsync(ws.cursor.data(), 0, ns * sizeof(uint32_t), st));
+		hipLaunchKernelGGL(k_scatter_hits, dim3(256), dim3(256), 0, st, ovf.data(), ws.counters.data() + 4, ovf_cap, unit_off,
+				   ws.cursor.data(), out->d_hits.data(), table_cap);
+		PGX_HIP(hipGetLastError());
+		const uint32_t *sort_start = read_start.data();
+		if (split) {
+			hipLaunchKernelGGL(k_merge_pieces, dim3((unsigned)std::min<uint64_t>((ns + 3) / 4, 256ull * 32)), dim3(256), 0, st, scratch.data(),
+					   read_start.data(), ws.piece_off.data(), rd->d_piece_parent.data(), rd->d_piece_qoff.data(), (uint32_t)ns,
+					   out->d_hits.data(), table_cap, cap);
+			hipLaunchKernelGGL(k_piece_ranges, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, rd->d_piece_first.data(),
+					   ws.piece_off.data(), (uint32_t)n, out->d_read_off.data(), out->d_read_cnt.data(), ws.parent_start.data());
+			PGX_HIP(hipGetLastError());
+			sort_start = ws.parent_start.data();
+		}
+		trace_point("group");
+		ws.ev.mark(3, st);
+
+		// per-read order (+ consensus): two reads per wavefront first; reads with 33..64 hits go through `mid_list` to
+		// the one-read-per-wave launch, which passes reads with more than 64 hits on to `big_list`
+		const int grid2 = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
+		hipLaunchKernelGGL(k_sort_consensus<32>, dim3(grid2), dim3(64 * kWavesPerBlock), 0, st, out->d_hits.data(), scratch.data(),
+				   sort_start, out->d_read_off.data(), out->d_read_cnt.data(), (unsigned long long)table_cap, (unsigned long long)cap, (uint32_t)n,
+				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv, rdp ? 1 : 0, lds_ok, d_recs, ws.mid_list.data(), mid_count);
+		trace_point("k_sort_consensus<32>");
+		hipLaunchKernelGGL(k_sort_consensus<64>, dim3(grid), dim3(64 * kWavesPerBlock), 0, st, out->d_hits.data(), scratch.data(),
+				   sort_start, out->d_read_off.data(), out->d_read_cnt.data(), (unsigned long long)table_cap, (unsigned long long)cap, (uint32_t)n,
+				   ws.mid_list.data(), mid_count, cv, rdp ? 1 : 0, lds_ok, d_recs, ws.big_list.data(), big_count);
+		PGX_HIP(hipGetLastError());
+		trace_point("k_sort_consensus<64>");
+		ws.ev.mark(4, st);
+
+		// the one wait of the step: counters (+ the gapped stage's list count, + the last read offset = slots used)
+		PGX_HIP(hipMemcpyAsync(h_cnt, ws.counters.data(), kNCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+		h_cnt[kNCounters] = 0;
+		if (dv.gapped)
+			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters, ws.gapped.big_count.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 1, out->d_read_off.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		PGX_HIP(hipStreamSynchronize(st));
+		H_ovf = h_cnt[4];
+		H = h_cnt[5] + H_ovf;
+		const uint64_t gap_listed = (uint32_t)h_cnt[kNCounters], gap_cap = ws.gapped.big_list.n;
+		bool again = false;
+		if (h_cnt[0] > cap) {
+			cap = h_cnt[0] + h_cnt[0] / 8;
+			again = true;
+		}
+		if (H_ovf > ovf_cap) {
+			ovf_cap = H_ovf + H_ovf / 8;
+			again = true;
+		}
+		if (dv.gapped && gap_listed > gap_cap) {
+			PGX_TRY(ws.gapped.big_list.ensure(gap_listed + gap_listed / 8));
+			again = true;
+		}
+		if (!again && H > table_cap) { // (H is only exact once the seed tables held everything)
+			table_cap = H + H / 16;
+			again = true;
+		}
+		if (!again)
 			break;
-		cap = std::max<uint64_t>(cap, h_cnt[0] + h_cnt[0] / 8);
-		ovf_cap = std::max<uint64_t>(ovf_cap, h_cnt[4] + h_cnt[4] / 8);
 	}
 	// h_cnt[0] counts reserved slots (chunks), h_cnt[5] the hits actually stored there
-	const uint64_t H_main = h_cnt[5], H_ovf = h_cnt[4], H = H_main + H_ovf;
-	g_ws.hit_cap_hint = std::max<uint64_t>(g_ws.hit_cap_hint, h_cnt[0] + h_cnt[0] / 16);
-	g_ws.ovf_cap_hint = std::max<uint64_t>(g_ws.ovf_cap_hint, H_ovf + H_ovf / 16);
+	ws.hit_cap_hint = std::max<uint64_t>(ws.hit_cap_hint, h_cnt[0] + h_cnt[0] / 16);
+	ws.ovf_cap_hint = std::max<uint64_t>(ws.ovf_cap_hint, H_ovf + H_ovf / 16);
+	ws.table_hint = std::max<uint64_t>(ws.table_hint, H + H / 16);
 	out->n_hits = (int64_t)H;
-	g_times.hits = (int64_t)H;
-	g_times.probes = (int64_t)h_cnt[1];
-	g_times.postings = (int64_t)h_cnt[2];
-	g_times.candidates = (int64_t)h_cnt[3];
-	g_times.survivors = (int64_t)h_cnt[6];
+	tm.hits = (int64_t)H;
+	tm.probes = (int64_t)h_cnt[1];
+	tm.postings = (int64_t)h_cnt[2];
+	tm.candidates = (int64_t)h_cnt[3];
+	tm.survivors = (int64_t)h_cnt[6];
+	tm.gapped_wide = (int64_t)(uint32_t)h_cnt[kNCounters];
+	tm.seed_extend_ms = ws.ev.ms(0, 1);
+	tm.gapped_ms = ws.ev.ms(1, 2);
+	tm.group_ms = ws.ev.ms(2, 3);
+	tm.sort_ms = ws.ev.ms(3, 4);
+	tm.total_ms = ws.ev.ms(0, 4);
 	// (PGX_HIT_LIMIT lowers the limit: tests use it to exercise the callers' batch halving)
 	const unsigned long long hit_limit = getenv("PGX_HIT_LIMIT") ? strtoull(getenv("PGX_HIT_LIMIT"), nullptr, 10) : (1ull << 32);
 	if (H >= hit_limit)
 		return fail(PGX_E_LIMIT, "%llu hits in one batch exceed the 32-bit slot limit: use smaller batches",
 			    (unsigned long long)H);
-
-	// group by read: exclusive scan of the per-read counts; only the overflow hits need a scatter
-	t.start();
-	// (per piece when the batch was searched piece by piece: the scan of the piece counts is the per-read layout too)
-	const uint32_t *unit_cnt = split ? g_ws.piece_cnt.data() : out->d_read_cnt.data();
-	uint32_t *unit_off = split ? g_ws.piece_off.data() : out->d_read_off.data();
-	const uint32_t n_part = (uint32_t)((ns + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
-	DevBuf<uint32_t> &partial = g_ws.partial, &cursor = g_ws.cursor;
-	PGX_TRY(partial.ensure(n_part));
-	hipLaunchKernelGGL(k_scan_partials, dim3(n_part), dim3(kScanBlock), 0, 0, unit_cnt, ns, partial.data());
-	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, 0, partial.data(), n_part);
-	hipLaunchKernelGGL(k_scan_final, dim3(n_part), dim3(kScanBlock), 0, 0, unit_cnt, ns, partial.data(), unit_off);
-	PGX_HIP(hipGetLastError());
-	PGX_TRY(out->d_hits.ensure(H ? H : 1));
-	if (H_ovf) {
-		PGX_TRY(cursor.ensure(ns));
-		PGX_HIP(hipMemsetAsync(cursor.data(), 0, ns * sizeof(uint32_t), 0));
-		const int g2 = (int)std::min<uint64_t>((H_ovf + 255) / 256, 256ull * 16);
-		hipLaunchKernelGGL(k_scatter_hits, dim3(g2), dim3(256), 0, 0, ovf.data(), H_ovf, unit_off, cursor.data(), out->d_hits.data());
-		PGX_HIP(hipGetLastError());
-	}
-	const uint32_t *sort_start = read_start.data();
-	if (split) {
-		hipLaunchKernelGGL(k_merge_pieces, dim3((unsigned)std::min<uint64_t>((ns + 3) / 4, 256ull * 32)), dim3(256), 0, 0, scratch.data(),
-				   read_start.data(), g_ws.piece_off.data(), rd->d_piece_parent.data(), rd->d_piece_qoff.data(), (uint32_t)ns,
-				   out->d_hits.data());
-		hipLaunchKernelGGL(k_piece_ranges, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, rd->d_piece_first.data(),
-				   g_ws.piece_off.data(), (uint32_t)n, out->d_read_off.data(), out->d_read_cnt.data(), g_ws.parent_start.data());
-		PGX_HIP(hipGetLastError());
-		sort_start = g_ws.parent_start.data();
-	}
-	g_times.group_ms = t.stop();
-	trace_point("group");
-
-	// per-read order (+ consensus)
-	t.start();
-	DevBuf<uint32_t> &big_list = g_ws.big_list, &big_count = g_ws.big_count;
-	PGX_TRY(big_list.ensure(n));
-	PGX_TRY(big_count.ensure(1));
-	PGX_HIP(hipMemsetAsync(big_count.data(), 0, sizeof(uint32_t), 0));
-	const ConsView cv = cons_view(db, rdp);
-	// two reads per wavefront first; reads with 33..64 hits go through `mid_list` to the one-read-per-wave launch,
-	// which passes reads with more than 64 hits on to `big_list`
-	DevBuf<uint32_t> &mid_list = g_ws.mid_list, &mid_count = g_ws.mid_count;
-	PGX_TRY(mid_list.ensure(n + 64ull * kWavesPerBlock * 256 * 8)); // + one open chunk per wave
-	PGX_TRY(mid_count.ensure(1));
-	PGX_HIP(hipMemsetAsync(mid_count.data(), 0, sizeof(uint32_t), 0));
-	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
-	const int grid2 = (int)std::min<uint64_t>((n + 2 * kWavesPerBlock - 1) / (2 * kWavesPerBlock), 256ull * 8);
-	hipLaunchKernelGGL(k_sort_consensus<32>, dim3(grid2), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
-			   sort_start, out->d_read_off.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, cv,
-			   rdp ? 1 : 0, lds_ok, d_recs, mid_list.data(), mid_count.data());
-	trace_point("k_sort_consensus<32>");
-	hipLaunchKernelGGL(k_sort_consensus<64>, dim3(grid), dim3(64 * kWavesPerBlock), 0, 0, out->d_hits.data(), scratch.data(),
-			   sort_start, out->d_read_off.data(), (uint32_t)n, mid_list.data(), mid_count.data(), cv, rdp ? 1 : 0,
-			   lds_ok, d_recs, big_list.data(), big_count.data());
-	PGX_HIP(hipGetLastError());
-	trace_point("k_sort_consensus<64>");
-	uint32_t n_big = 0;
-	PGX_TRY(big_count.download(&n_big, 1));
+	const uint32_t n_big = (uint32_t)h_cnt[8];
 	if (n_big) {
 		// more than 64 hits (or reads too long for the packed keys): segmented radix sorts, any size (bigreads.hip)
-		PGX_TRY(sort_big_reads(out->d_hits.data(), scratch.data(), sort_start, out->d_read_off.data(),
-				       out->d_read_cnt.data(), big_list.data(), n_big));
+		const uint32_t *sort_start = split ? ws.parent_start.data() : read_start.data();
+		ws.ev.mark(4, st);
+		PGX_TRY(sort_big_reads(out->d_hits.data(), scratch.data(), sort_start, out->d_read_off.data(), out->d_read_cnt.data(),
+				       ws.big_list.data(), n_big, dv.gapped != 0));
 		if (rdp) {
-			hipLaunchKernelGGL(k_consensus_serial, dim3((n_big + 63) / 64), dim3(64), 0, 0, out->d_hits.data(),
-					   out->d_read_off.data(), out->d_read_cnt.data(), big_list.data(), n_big, cv, d_recs);
+			hipLaunchKernelGGL(k_consensus_serial, dim3((n_big + 63) / 64), dim3(64), 0, 0, out->d_hits.data(), out->d_read_off.data(),
+					   out->d_read_cnt.data(), ws.big_list.data(), n_big, cv, d_recs);
 			PGX_HIP(hipGetLastError());
 		}
+		ws.ev.mark(5, 0);
+		PGX_HIP(hipDeviceSynchronize());
+		const float extra = ws.ev.ms(4, 5);
+		tm.sort_ms += extra;
+		tm.total_ms += extra;
 	}
-	g_times.sort_ms = t.stop();
-	g_times.total_ms = total.stop();
+	t_times = tm;
 	return 0;
 }
 
@@ -1894,14 +2007,19 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 {
 	if (!db || !reads || !rdp)
 		return fail(PGX_E_ARG, "pgx_classify_consensus: null argument");
-	PGX_TRY(g_ws.recs.ensure((size_t)reads->n + 1));
-	pgx_hits *h = hits_out ? new pgx_hits() : &g_ws.hits;
-	int rc = search_pipeline(db, reads, rdp, h, g_ws.recs.data());
+	Workspace *ws = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(db->search_mu);
+		PGX_TRY(workspace_of(db, &ws));
+		PGX_TRY(ws->recs.ensure((size_t)reads->n + 1));
+	}
+	pgx_hits *h = hits_out ? new pgx_hits() : &ws->hits;
+	int rc = search_pipeline(db, reads, rdp, h, ws->recs.data());
 	if (rc == 0 && out) {
 		if (cap < reads->n)
 			rc = fail(PGX_E_ARG, "record buffer too small");
 		else
-			rc = g_ws.recs.download(out, (size_t)reads->n);
+			rc = ws->recs.download(out, (size_t)reads->n);
 	}
 	if (hits_out) {
 		if (rc < 0)
@@ -1910,6 +2028,15 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 			*hits_out = h;
 	}
 	return rc;
+}
+
+int pgx_db_set_ungapped(pgx_db *db, int ungapped)
+{
+	if (!db)
+		return fail(PGX_E_ARG, "pgx_db_set_ungapped: null argument");
+	std::lock_guard<std::mutex> lock(db->search_mu);
+	db->ungapped = ungapped != 0;
+	return 0;
 }
 
 void pgx_hits_close(pgx_hits *h) { delete h; }
@@ -1933,11 +2060,22 @@ int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap)
 	return 0;
 }
 
+int pgx_hits_read_counts(const pgx_hits *h, int64_t *out, int64_t cap)
+{
+	if (!h || !out || cap < h->n_reads)
+		return fail(PGX_E_ARG, "pgx_hits_read_counts: bad argument");
+	std::vector<uint32_t> tmp((size_t)h->n_reads);
+	PGX_TRY(h->d_read_cnt.download(tmp.data(), tmp.size()));
+	for (size_t i = 0; i < tmp.size(); i++)
+		out[i] = tmp[i];
+	return 0;
+}
+
 int pgx_last_stage_times(pgx_stage_times *out)
 {
 	if (!out)
 		return fail(PGX_E_ARG, "pgx_last_stage_times: null argument");
-	*out = g_times;
+	*out = t_times;
 	return 0;
 }
 }

@@ -1,6 +1,7 @@
 // Internal object model of libpangea_hip: what lives in HBM for one process / one GPU.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -32,6 +33,9 @@ struct pgx_db {
 	pgx::DevBuf<uint32_t> d_amb_blk; // databases with ambiguity letters: one bit per 512-base block that holds one
 	int index_bits = 0;
 	int64_t n_postings = 0;
+	std::shared_ptr<void> work; // classify.hip: the handle's search workspace (stream, tables, counters), made on first use
+	std::mutex search_mu;       // searches through one handle are serialised; different handles share nothing
+	bool ungapped = false; // pgx_db_set_ungapped: searches through this handle stop after the ungapped stage (spec v1)
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
 	// databases without ambiguity: 12-byte records {posting, database bases left of the 16-mer, bases right of it}, the
 	// stream k_seed_extend deals from (one contiguous piece per bucket instead of two)
@@ -222,7 +226,60 @@ int consensus_device(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp,
 
 // bigreads.hip: spec order + 500-subject cut for reads with more than 64 hits
 int sort_big_reads(pgx_hit *hits, const pgx_hit *scratch, const uint32_t *read_start, const uint32_t *off, uint32_t *read_cnt,
-		   const uint32_t *big_list, uint32_t n_big);
+		   const uint32_t *big_list, uint32_t n_big, bool gapped);
+
+// columns of a hit that follow from the stored ones (include/pangea_hip.h: pgx_hit)
+__host__ __device__ inline int hit_qspan(const pgx_hit &h) { return h.qend - h.qstart + 1; }
+__host__ __device__ inline int hit_sspan(const pgx_hit &h) { return (h.send > h.sstart ? h.send - h.sstart : h.sstart - h.send) + 1; }
+__host__ __device__ inline int hit_diffs(const pgx_hit &h)
+{
+	const int t = hit_qspan(h) + hit_sspan(h);
+	return (t - 2 * h.score - (t & 1)) / 6;
+}
+__host__ __device__ inline int hit_gaps(const pgx_hit &h) { return hit_diffs(h) - (int)h.mismatch; }
+__host__ __device__ inline int hit_length(const pgx_hit &h) { return (hit_qspan(h) + hit_sspan(h) + hit_gaps(h)) / 2; }
+
+// Stage probes (PGX_SEED_STOP / PGX_SORT_STOP truncate the kernels after a stage: tools/probe_stages.py) exist only in
+// builds made with -DPGX_STAGE_PROBES; the shipped kernels carry no such branches.
+#ifdef PGX_STAGE_PROBES
+#define PGX_DBG_STOP(v) ((v).dbg_stop)
+#define PGX_SORT_DBG(v) ((v).dbg)
+#else
+#define PGX_DBG_STOP(v) 0
+#define PGX_SORT_DBG(v) 0
+#endif
+
+struct DbView {
+	const uint64_t *words, *amb;
+	const uint32_t *seq_off, *blk_subj, *bucket_off, *postings;
+	const uint4 *blk_info;
+	const uint3 *post_ctx;
+	const uint32_t *amb_blk; // one bit per 512-base block with an ambiguity letter (null: the database has none)
+	uint32_t n_seq;
+	int bits;
+	int gapped;   // spec v2: the seed stage hands over initial HSPs (score field = offset of the seed run in the HSP) to gapped.hip
+	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
+};
+
+struct ReadsView {
+	const uint64_t *fwd, *rc, *fwd_amb, *rc_amb;
+	const uint32_t *len, *woff;
+	uint32_t n;           // reads this launch works on
+	const uint32_t *list; // their ids (null: 0 .. n-1): a batch is searched class by class (flag words, ambiguity)
+};
+
+
+constexpr uint32_t kFragmented = 0xFFFFFFFFu; // read_start of a read whose hits went to the overflow table
+
+// gapped.hip: spec v2 S3b on the initial HSPs of a seed-stage table (main table addressed through read_start / read_cnt,
+// overflow table flat), in place; long reads and extensions with many differences go through `big` lists
+struct GappedWork {
+	DevBuf<unsigned long long> big_list;
+	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats)
+};
+int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint32_t *read_start, const uint32_t *read_cnt,
+		 pgx_hit *ovf_table, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
+		 unsigned long long hit_cap, GappedWork &gw, hipStream_t stream);
 
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
 __host__ __device__ inline int pident_hundredths(int matches, int length)

@@ -20,7 +20,7 @@
 
 namespace pgx {
 
-void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_nseq, std::string &evalue, std::string &bits);
+void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, std::string &evalue, std::string &bits);
 
 // ------------------------------------------------------------------------------------------ Perl semantics (host)
 static inline bool p_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
@@ -192,8 +192,8 @@ __global__ void k_mc_filter_batch(const pgx_consensus_rec *__restrict__ recs, co
 	} else if (w >= 0) {
 		ln = 1;
 		const pgx_hit h = hits[w];
-		const int len = h.qend - h.qstart + 1;
-		const int hund = pident_hundredths(len - h.mismatch, len);
+		const int len = hit_length(h);
+		const int hund = pident_hundredths(len - hit_diffs(h), len);
 		const uint32_t L = read_len[i];
 		const uint32_t smin = L <= max_len ? s_min[L] : 0xFFFFFFFFu;
 		ps = hund >= h_min && (uint32_t)h.score >= smin;
@@ -519,7 +519,7 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
 			seen[reads->h_len[(size_t)r]] = 1;
 		std::string evt, bst;
 		auto ok_score = [&](int score, uint32_t L) {
-			format_score_columns(score, L, db->n_bases, db->n_seq, evt, bst);
+			format_score_columns(score, L, db->n_bases, db->n_seq, !db->ungapped, evt, bst);
 			return !(perl_num(evt) > p.ev) && !(perl_num(bst) < p.bits);
 		};
 		for (uint32_t L = 0; L <= max_len; L++) {

@@ -1014,13 +1014,14 @@ static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out
 }
 
 // ------------------------------------------------------------------------------------------ pieces of reads with long N runs
-// Spec S3: an extension stops once the running score is more than X = 10 below its best, and a letter that is not
-// A/C/G/T matches nothing (- 2 per column): no HSP can hold a letter of a run of kSplitRun = 6 or more such letters,
-// and no seed overlaps one.  The stretches between such runs can therefore be searched as reads of their own (most
+// Spec S3: a letter that is not A/C/G/T matches nothing, so every alignment pays at least 2 for each such letter of
+// the read it spans; the gapped extension (X = 54, compared with the best score 19 differences earlier) abandons every
+// path inside a run of kSplitRun = 28 or more of them (2 * 28 > 54, 28 >= 19), the ungapped one (X = 10) long before,
+// and no seed overlaps one: no hit holds a letter of such a run.  The stretches between such runs can therefore be searched as reads of their own (most
 // of them free of ambiguity letters: the plain kernels, the small flag classes) and their hits put back per read
 // with the query coordinates shifted (search_pipeline).  This is the shape trim2 -g hands over: two mates joined
 // by 100 or 189 N's (Trim/trim2.4.pl:228-245, :502-505).  Stretches shorter than a seed word hold no hit and are dropped.
-constexpr uint32_t kSplitRun = 6, kMinPiece = 28;
+constexpr uint32_t kSplitRun = 28, kMinPiece = 28;
 
 // f(start, length) for every stretch of read letters [s, s + L) kept by the rule above, left to right
 template <typename F> __device__ __forceinline__ void for_pieces(const unsigned char *__restrict__ letters, uint64_t s, uint64_t L, F f)

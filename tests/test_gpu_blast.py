@@ -315,6 +315,13 @@ def test_random_mixtures_match_oracle(pg, oracle_bin, tmp_path, seed):
                 w = list(s[o:o + L])
         for p_ in rng.sample(range(len(w)), rng.choice([0, 0, 1, 2, 3, len(w) // 20])):
             w[p_] = rng.choice("ACGTN")
+        if rng.random() < 0.35 and len(w) > 40:       # 454-style: insertions and deletions (the gapped stage, spec v2)
+            for _ in range(rng.choice([1, 1, 2, 3])):
+                p_ = rng.randrange(1, len(w) - 1)
+                if rng.random() < 0.5:
+                    del w[p_:p_ + rng.choice([1, 1, 2, 4])]
+                else:
+                    w[p_:p_] = [rng.choice("ACGT") for _ in range(rng.choice([1, 1, 2, 4]))]
         w = "".join(w)
         if rng.random() < 0.5:
             w = "".join(comp.get(c, "N") for c in reversed(w))
@@ -325,6 +332,94 @@ def test_random_mixtures_match_oracle(pg, oracle_bin, tmp_path, seed):
     assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want)], timeout=600)[0] == 0
     assert len(want.read_bytes()) > 50000
     assert _blast_text(pg, db, rd, tmp_path, "fz") == want.read_bytes()
+
+
+def test_ungapped_flag_gives_spec_v1(pg, workload, oracle_bin, tmp_path):
+    """`blastn -ungapped` (BLAST's own flag) stops after the ungapped stage: the round-1 tables, gapopen 0 everywhere;
+    through the file verb and through a database handle."""
+    from pangea_plus_amd import _capi
+    want = tmp_path / "v1.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(workload / "reads.fa"), "-db", str(workload / "db.fa"), "-outfmt", "6",
+                    "-out", str(want), "-num_threads", "8", "-ungapped"], timeout=600)[0] == 0
+    v1 = want.read_bytes()
+    assert v1 != open(workload / "oracle.tsv", "rb").read() and all(l.split(b"\t")[5] == b"0" for l in v1.splitlines())
+    pg.makeblastdb(str(workload / "db.fa"), str(tmp_path / "db"))
+    out = tmp_path / "hits.tsv"
+    pg.blastn(str(workload / "reads.fa"), str(tmp_path / "db"), str(out), ungapped=True)
+    assert out.read_bytes() == v1
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.set_ungapped(True)
+    reads = pg.Reads.from_synth(cfg, 0, N_READS)
+    assert _capi.blast_search(db, reads).format(db, reads) == v1
+    db.set_ungapped(False)
+    assert _capi.blast_search(db, reads).format(db, reads) == open(workload / "oracle.tsv", "rb").read()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_reads_with_insertions_and_deletions(pg, oracle_bin, tmp_path, seed):
+    """Spec v2: 454 / Ion-style reads (homopolymer length errors, random indels) and 1 400-base queries with indels against
+    a 16S-like family: gapopen > 0 rows, seeds on either side of a gap merged into one row (S3c), the one-wavefront-per-HSP
+    kernel for the long queries and for sides with more than 15 differences."""
+    import random
+    rng = random.Random(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    anc = "".join(rng.choice("ACGT") for _ in range(1500))
+    # homopolymer runs, where length errors live
+    for _ in range(25):
+        a = rng.randrange(0, 1450)
+        anc = anc[:a] + rng.choice("ACGT") * rng.randrange(3, 9) + anc[a + 6:]
+    anc = anc[:1500]
+    seqs = []
+    for i in range(60):
+        s = list(anc)
+        for p_ in rng.sample(range(len(s)), 30 + (i % 5) * 25):
+            s[p_] = rng.choice("ACGT")
+        for _ in range(i % 4):
+            p_ = rng.randrange(10, len(s) - 10)
+            if rng.random() < 0.5:
+                del s[p_:p_ + rng.randrange(1, 6)]
+            else:
+                s[p_:p_] = [rng.choice("ACGT") for _ in range(rng.randrange(1, 6))]
+        seqs.append("".join(s))
+    db = tmp_path / "fam.fa"
+    db.write_text("".join(">gi|%d|x|s%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    reads = []
+    for i in range(500):
+        L = rng.choice([100, 150, 150, 250, 400, 400, 1400])
+        s = rng.choice(seqs)
+        o = rng.randrange(0, max(1, len(s) - L))
+        w = list(s[o:o + L])
+        for p_ in rng.sample(range(len(w)), rng.randrange(0, 1 + len(w) // 40)):
+            w[p_] = rng.choice("ACGT")
+        for _ in range(rng.choice([0, 1, 1, 2, 3, 6]) * (1 + L // 500)):
+            p_ = rng.randrange(1, len(w) - 1)
+            if rng.random() < 0.5:           # homopolymer length error
+                run = 1
+                while p_ + run < len(w) and w[p_ + run] == w[p_]:
+                    run += 1
+                if rng.random() < 0.5 and run > 1:
+                    del w[p_]
+                else:
+                    w.insert(p_, w[p_])
+            elif rng.random() < 0.5:
+                del w[p_:p_ + rng.choice([1, 2, 3, 7])]
+            else:
+                w[p_:p_] = [rng.choice("ACGT") for _ in range(rng.choice([1, 2, 3, 7]))]
+        w = "".join(w)
+        if i % 2:
+            w = "".join(comp[c] for c in reversed(w))
+        reads.append(">i%d\n%s\n" % (i, w))
+    rd = tmp_path / "indel_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "indel_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want), "-num_threads", "8"],
+                   timeout=900)[0] == 0
+    rows = want.read_bytes().splitlines()
+    gapped = [r for r in rows if r.split(b"\t")[5] != b"0"]
+    assert len(rows) > 10000 and len(gapped) > len(rows) // 4
+    assert max(int(r.split(b"\t")[5]) for r in gapped) >= 8
+    assert _blast_text(pg, db, rd, tmp_path, "indel") == want.read_bytes()
 
 
 def test_command_lines_with_the_reference_flags(workload, tmp_path):
