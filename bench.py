@@ -262,7 +262,8 @@ def main():
                              "alg_bytes_per_launch": alg_bytes / args.steps, "kernel_ms_per_launch": kernel_ms / args.steps,
                              "survey_8d": survey_8d(last.hits / B, world * B * args.steps / dt / world),
                              "random_line_roof": line_roof},
-                "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "group": last.group_ms,
+                "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "gapped": last.gapped_ms, "gapped_wide_hsps": last.gapped_wide,
+                                        "group": last.group_ms,
                                         "sort_consensus": last.sort_ms, "total": last.total_ms},
                 "per_read_last_step": {"probes": last.probes / B, "postings": last.postings / B,
                                        "filter_survivors": last.survivors / B, "seed_runs": last.candidates / B, "hits": last.hits / B},

@@ -80,7 +80,15 @@ void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t
 			int32_t mism = 0;
 			for (int32_t k = bl; k <= br; k++)
 				mism += !is_match(q, s, d, k);
-			emit(ctx, bl, br, (j - i) + best + bestr, mism, i);
+			/* S3b anchor: the exact run around the middle of the HSP -- the first base of the run of matches that holds
+			 * the last matching position at or before the middle column (an extension from the middle costs the least:
+			 * its work grows with the square of the differences on a side) */
+			int32_t anchor = bl + (br - bl) / 2;
+			while (!is_match(q, s, d, anchor))
+				anchor--; /* (bl is a match) */
+			while (anchor > bl && is_match(q, s, d, anchor - 1))
+				anchor--;
+			emit(ctx, bl, br, (j - i) + best + bestr, mism, anchor);
 			covered = br + 1;
 		}
 		i = j;

@@ -35,6 +35,9 @@
 #define G_DMAX 1000
 #define G_NONE (-0x3FFFFFFF)
 
+/* exploration statistics (single-threaded runs only): sides by last difference count explored, cells evaluated */
+long long o_greedy_depth_hist[64], o_greedy_cells;
+
 static inline int g_match(uint8_t a, uint8_t b)
 {
 	return a < 4 && a == b;
@@ -49,8 +52,10 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 		i++;
 	out->i = out->j = i;
 	out->s2 = 2 * i;
-	if (i == M || i == N)
+	if (i == M || i == N) {
+		o_greedy_depth_hist[0]++;
 		return; /* a sequence end: every further cell only loses */
+	}
 	const int32_t dcap = G_DMAX;
 	/* per d: R and the move taken, diagonals -d .. d at index k + d */
 	int32_t *Rprev = (int32_t *)malloc((size_t)(2 * dcap + 3) * sizeof(int32_t));
@@ -93,6 +98,7 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 				if (ub <= best)
 					dead = 1;
 			}
+			o_greedy_cells += !dead;
 			if (dead) {
 				RC(k) = G_NONE;
 				mv[d][k + d] = 0;
@@ -125,6 +131,7 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 		L = nl;
 		U = nu;
 	}
+	o_greedy_depth_hist[d < 63 ? d : 63]++;
 	/* traceback from the best cell: the moves of the path (bits 0-1 kind, bit 2: the cell slid over matches after it) */
 	out->i = best_i;
 	out->j = best_i - best_k;

@@ -167,6 +167,17 @@ template <bool AMB, int NW> struct DenseMask {
 		return r;
 	}
 	__device__ __forceinline__ static int win_first_ge(const Win &w, int n) { return first_set_ge(w.w, n); }
+	// flagged positions of [a, b) that lie inside [lo, hi)
+	__device__ __forceinline__ int count_range(int a, int b) const
+	{
+		a = a > lo ? a : lo;
+		b = b < hi ? b : hi;
+		int c = 0;
+#pragma unroll
+		for (int k = 0; k < NW; k++)
+			c += __popcll(m[k] & from(a - 64 * k) & below(b - 64 * k));
+		return c;
+	}
 	// smallest flagged position >= pos, or hi
 	__device__ __forceinline__ int first_ge(int pos) const
 	{
@@ -260,6 +271,7 @@ template <bool AMB> struct LazyMask {
 		lo = d.lo;
 		hi = d.hi;
 	}
+	__device__ __forceinline__ int count_range(int, int) const { return 15; } // (long reads go to the wide gapped kernel anyway)
 	__device__ __forceinline__ int first_ge(int pos) const
 	{
 		if (pos >= hi)
@@ -358,7 +370,7 @@ __device__ __forceinline__ uint4 pack_hit(const pgx_hit &h)
 {
 	const uint32_t minus = h.sstart > h.send;
 	return make_uint4((uint32_t)h.subject, (uint32_t)h.sstart, (uint32_t)h.qstart | ((uint32_t)h.qend << 16) | (minus << 31),
-			  (uint32_t)h.score | ((uint32_t)h.mismatch << 16));
+			  (uint32_t)h.score | ((uint32_t)h.mismatch << 16) | ((uint32_t)h.gapopen << 24));
 }
 
 __device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
@@ -372,8 +384,8 @@ __device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
 	const int span = h.qend - h.qstart;
 	h.send = (c.z >> 31) ? h.sstart - span : h.sstart + span;
 	h.score = (int32_t)(c.w & 0xFFFFu);
-	h.mismatch = (uint16_t)(c.w >> 16);
-	h.gapopen = 0;
+	h.mismatch = (uint16_t)((c.w >> 16) & 0xFFu); // (ungapped hits of <= 512-base reads: at most 170 mismatches)
+	h.gapopen = (uint16_t)(c.w >> 24);
 	return h;
 }
 
@@ -531,11 +543,26 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 			pgx_hit h;
 			h.read = (int32_t)read;
 			h.subject = (int32_t)s;
-			// spec v2: this is an INITIAL HSP; the gapped stage (gapped.hip) extends it from the first base of its seed
-			// run, whose offset from the HSP's start travels in the score field
-			h.score = db.gapped ? pos - bl : len + best + bestr;
-			h.mismatch = (uint16_t)(db.gapped ? 0 : mm_best + mmr_best);
+			// spec v2: this is an INITIAL HSP; the gapped stage (gapped.hip) extends it from its ANCHOR: the first base of
+			// the run of matches that holds the last matching position at or before the HSP's middle column (S3b; an
+			// extension from the middle costs the least: its work grows with the square of the differences on a side).
+			// The anchor's offset from the HSP's start travels in the score field.
+			h.score = len + best + bestr;
+			h.mismatch = (uint16_t)(mm_best + mmr_best);
 			h.gapopen = 0;
+			if (db.gapped) {
+				int q = bl + (br - bl) / 2;
+				while (M.first_ge(q) == q)
+					q--; // (bl is a match)
+				int anchor = M.last_lt(q) + 1;
+				anchor = anchor > bl ? anchor : bl;
+				h.score = anchor - bl;
+				// work estimate for the gapped stage (it groups sides of similar cost): mismatches of the diagonal left of
+				// the anchor and right of it, capped at 15
+				const int ml = M.count_range(D.lo, anchor), mr = M.count_range(anchor, D.hi);
+				h.mismatch = (uint16_t)(ml < 15 ? ml : 15);
+				h.gapopen = (uint16_t)(mr < 15 ? mr : 15);
+			}
 			const int64_t sl = D.dstart + bl - (int64_t)s_start + 1, sr = D.dstart + br - (int64_t)s_start + 1;
 			if (!strand) {
 				h.qstart = bl + 1;
@@ -1847,7 +1874,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			ReadsView all = rv;
 			all.n = (uint32_t)ns;
 			PGX_TRY(gapped_stage(dv, all, scratch.data(), rs_ptr, rc_ptr, ovf.data(), ws.counters.data() + 4, ovf_cap, long_reads, cap,
-					     ws.gapped, st));
+					     (int)sr->max_len, ws.gapped, st));
 			trace_point("gapped_stage");
 		}
 		ws.ev.mark(2, st);

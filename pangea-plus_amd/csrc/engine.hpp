@@ -276,10 +276,11 @@ constexpr uint32_t kFragmented = 0xFFFFFFFFu; // read_start of a read whose hits
 struct GappedWork {
 	DevBuf<unsigned long long> big_list;
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats)
+	DevBuf<uint2> side_main, side_ovf; // per table slot: the left side's extension, parked until the right side is done
 };
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint32_t *read_start, const uint32_t *read_cnt,
 		 pgx_hit *ovf_table, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, GappedWork &gw, hipStream_t stream);
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream);
 
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
 __host__ __device__ inline int pident_hundredths(int matches, int length)

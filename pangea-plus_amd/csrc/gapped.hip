@@ -27,12 +27,17 @@ namespace pgx {
 
 constexpr int kGX2 = 108;     // 2 X
 constexpr int kGLag = 19;     // floor((X + 1/2) / 3) + 1: the X-drop test looks at the best score 19 differences earlier
-constexpr int kGFastD = 15;   // differences per side of the lane-per-HSP kernel (< kGLag: its X-drop reference is 0)
-constexpr int kGFastLen = 512; // read length up to which a lane's 16-bit positions are enough
+constexpr int kGFastD = 23;   // differences per side of the lane-per-HSP kernel (99.997 % of the sides of 150-base reads at 6 % divergence)
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
 constexpr uint32_t kCellNone = 0xFFFFFFFFu;
-static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
+static_assert(kGFastD - kGLag <= 4, "the lane-per-HSP kernel keeps the best scores of the first five rows");
+
+__device__ __forceinline__ void lds_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
 
 struct GapSeqs {
 	const uint64_t *rw, *ra;   // read strand: words, spaced ambiguity flags (or null)
@@ -77,81 +82,35 @@ template <int DIR> __device__ __forceinline__ int lcp(const GapSeqs &s, int qp, 
 }
 
 // ------------------------------------------------------------------------------------------ one lane per HSP
-// cell: bits 0-15 i, 16-20 mismatches, 21-25 gap openings, 26-27 kind of the last difference (0 mismatch, 1 gap in the
-// subject row, 2 gap in the query row), 28: letters matched after it
-template <int DIR>
-__device__ __forceinline__ bool greedy_fast(uint32_t *__restrict__ cells, const GapSeqs &s, int q0, int64_t d0, int M, int N, Side &out)
+// Work per HSP is quadratic in its differences and varies a lot (0 to ~500 cells).  History of this kernel, 10 M reads
+// (282 M HSPs) per launch: nested per-lane loops, sequences read through the caches: 1 080 ms with a 15-difference limit
+// (3.6 % of the HSPs fell to the wide kernel); a per-lane state machine with dynamic refill (one cell per lane per trip):
+// 340 ms, then 713 ms with the sequences in LDS at 1.75 waves per SIMD -- 470 vector instructions per trip, almost all of
+// it bookkeeping of a state machine whose rare per-lane events happen in some lane on every trip.  Now: the loops over d
+// and k are WAVE-UNIFORM, which lets the row of a lane live in registers, and a wavefront first orders its HSPs by the
+// seed stage's work estimate so that the 64 lanes of a round have about the same number of rows.
+// The two sequences of a lane's HSP are staged in LDS when the lane takes it (read strand; database window around the
+// anchor: read length + 2 x kGFastD + slack bases): fetched from the caches per cell, 64 lanes x 2 lines each, they made the
+// kernel wait on L2 (first version: 340 ms per 10 M reads; 2.8 TB of line traffic).  HSPs that touch an ambiguity letter
+// (read or database window) go to the wide kernel, which applies the flag words.
+__device__ __forceinline__ uint32_t lds_window16(const uint32_t *w, int pos)
 {
-	auto slide = [&](int i, int j) {
-		const int cap = M - i < N - j ? M - i : N - j;
-		return lcp<DIR>(s, q0 + DIR * i, d0 + DIR * j, cap);
-	};
-	const int i0 = slide(0, 0);
-	out.i = out.j = i0;
-	out.s2 = 2 * i0;
-	out.mism = out.gopen = 0;
-	if (i0 == M || i0 == N)
-		return true;
-	constexpr int C = kGFastD + 1;
-#pragma unroll
-	for (int c = 0; c < kGFastCells; c++)
-		cells[c] = kCellNone;
-	cells[C] = (uint32_t)i0 | (i0 > 0 ? 1u << 28 : 0u);
-	int best = 2 * i0, L = 0, U = 0;
-	for (int d = 1; d <= kGFastD; d++) {
-		int nl = 1 << 20, nu = -(1 << 20);
-		uint32_t prev = kCellNone, cur = kCellNone; // cells outside [L, U] are kCellNone
-		for (int k = L - 1; k <= U + 1; k++) {
-			const uint32_t nxt = cells[C + k + 1];
-			int v = -1, par = 0;
-			uint32_t p = 0;
-			if (cur != kCellNone) {
-				v = (int)(cur & 0xFFFFu) + 1;
-				p = cur;
-			}
-			if (prev != kCellNone && (int)(prev & 0xFFFFu) + 1 > v) {
-				v = (int)(prev & 0xFFFFu) + 1;
-				par = 1;
-				p = prev;
-			}
-			if (nxt != kCellNone && (int)(nxt & 0xFFFFu) > v) {
-				v = (int)(nxt & 0xFFFFu);
-				par = 2;
-				p = nxt;
-			}
-			int ii = v, jj = v - k;
-			const int ub = (2 * M - k < 2 * N + k ? 2 * M - k : 2 * N + k) - 6 * d;
-			uint32_t nc = kCellNone;
-			if (v >= 0 && ii <= M && jj <= N && jj >= 0 && ii + jj - 6 * d >= -kGX2 && ub > best) {
-				const int run = slide(ii, jj);
-				ii += run;
-				jj += run;
-				const uint32_t pk = (p >> 26) & 3u, pslid = (p >> 28) & 1u;
-				const uint32_t mism = ((p >> 16) & 31u) + (par == 0 ? 1u : 0u);
-				const uint32_t gopen = ((p >> 21) & 31u) + ((par != 0 && !(pk == (uint32_t)par && !pslid)) ? 1u : 0u);
-				nc = (uint32_t)ii | (mism << 16) | (gopen << 21) | ((uint32_t)par << 26) | (run > 0 ? 1u << 28 : 0u);
-				const int s2 = ii + jj - 6 * d;
-				if (s2 > best) {
-					best = s2;
-					out.i = ii;
-					out.j = jj;
-					out.s2 = s2;
-					out.mism = (int)mism;
-					out.gopen = (int)gopen;
-				}
-				nl = k < nl ? k : nl;
-				nu = k > nu ? k : nu;
-			}
-			cells[C + k] = nc;
-			prev = cur;
-			cur = nxt;
-		}
-		if (nl > nu)
-			return true;
-		L = nl;
-		U = nu;
-	}
-	return false; // cells still alive after kGFastD differences: the wide kernel takes this HSP
+	const int i = pos >> 4;
+	const uint64_t v = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+	return (uint32_t)(v >> ((pos & 15) * 2));
+}
+
+// up to 16 letters from read position qp / window position dp on, in direction dir: how many match (0 .. take)
+__device__ __forceinline__ int lcp_chunk(const uint32_t *rd, const uint32_t *db, int dir, int qp, int dp, int take)
+{
+	const int back = dir > 0 ? 0 : take - 1;
+	const uint32_t x = lds_window16(rd, qp - back) ^ lds_window16(db, dp - back);
+	uint32_t y = (x | (x >> 1)) & 0x55555555u;
+	if (take < 16)
+		y &= (1u << (2 * take)) - 1u;
+	const uint32_t yb = y << (2 * (16 - take));
+	const int fwd = y ? (__ffs((int)y) - 1) >> 1 : take, bwd = yb ? __clz((int)yb) >> 1 : take;
+	return dir > 0 ? fwd : bwd;
 }
 
 struct GapView {
@@ -159,6 +118,7 @@ struct GapView {
 	const uint32_t *len, *woff;
 	const uint64_t *dbw, *dba;
 	const uint32_t *seq_off;
+	const uint32_t *amb_blk; // one bit per 512-base block of the database that holds an ambiguity letter (or null)
 };
 
 // the initial HSP (seed stage, gapped mode): score = offset of the first base of the seed run from the HSP's start, on
@@ -213,86 +173,322 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 	*hp = o;
 }
 
-__device__ __forceinline__ void gapped_one(const GapView &v, pgx_hit *hp, uint32_t *cells, unsigned long long *big_list,
-					   uint32_t *big_count, uint32_t big_cap)
+// One side of a lane's HSP, all 64 lanes in step: the loops over d and k are wave-uniform, so the row R(d, .) of a lane
+// lives in REGISTERS (kGFastCells words, indexed by the unrolled k) and is updated in place, k ascending.  Lanes whose
+// cell is dead, or that have finished, idle for that step; the caller groups HSPs of similar cost to keep that rare.
+// cell: bits 0-15 i, 16-20 mismatches, 21-25 gap openings, 26-27 kind of the last difference (0 mismatch, 1 gap in the
+// subject row, 2 gap in the query row), 28: letters matched after it.
+// Returns false for a lane whose cells are still alive after kGFastD differences.
+__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int dir, int q0, int d0, int M, int N,
+					     Side &out)
 {
-	const pgx_hit h = *hp;
-	const Anchor a = anchor_of(v, h);
-	bool done = false;
-	if (a.L <= kGFastLen) {
-		Side l, r;
-		done = greedy_fast<-1>(cells, a.s, a.qa - 1, a.S0 + a.sa - 1, a.qa, a.sa, l);
-		if (done)
-			done = greedy_fast<+1>(cells, a.s, a.qa, a.S0 + a.sa, a.L - a.qa, a.slen - a.sa, r);
-		if (done)
-			write_gapped(hp, h, a, l, r);
+	auto slide = [&](int &ii, int &jj) {
+		for (;;) {
+			const int cap = M - ii < N - jj ? M - ii : N - jj;
+			const int take = cap < 16 ? cap : 16;
+			if (take <= 0)
+				break;
+			const int run = lcp_chunk(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, take);
+			ii += run;
+			jj += run;
+			if (run < 16)
+				break;
+		}
+	};
+	out.i = out.j = out.s2 = out.mism = out.gopen = 0;
+	int i0 = 0, j0 = 0;
+	if (on)
+		slide(i0, j0);
+	out.i = out.j = i0;
+	out.s2 = 2 * i0;
+	bool live = on && !(i0 == M || i0 == N); // this lane still has cells to explore
+	uint32_t R[kGFastCells];
+#pragma unroll
+	for (int c = 0; c < kGFastCells; c++)
+		R[c] = kCellNone;
+	constexpr int C = kGFastD + 1;
+	R[C] = live ? ((uint32_t)i0 | (i0 > 0 ? 1u << 28 : 0u)) : kCellNone;
+	int best = 2 * i0;
+	int T0 = best, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+	int Lw = 0, Uw = 0; // wave-wide range of diagonals that hold a live cell
+	bool over = false;
+	for (int d = 1; __ballot(live) != 0ull; d++) {
+		if (d > kGFastD) {
+			over = live;
+			break;
+		}
+		const int td = d - kGLag;
+		const int tcmp = td < 0 ? 0 : (td == 0 ? T0 : td == 1 ? T1 : td == 2 ? T2 : td == 3 ? T3 : T4);
+		uint32_t prev = kCellNone; // the old value of the cell left of the one being written
+		bool any = false;
+		int nl = 1 << 20, nu = -(1 << 20);
+#pragma unroll
+		for (int c = 1; c < kGFastCells - 1; c++) {
+			const int k = c - C;
+			if (k < Lw - 1 || k > Uw + 1) // wave-uniform: no lane has a parent for this diagonal
+				continue;
+			const uint32_t cur = R[c], nxt = R[c + 1];
+			int v = -1, par = 0;
+			uint32_t p = 0;
+			if (cur != kCellNone) {
+				v = (int)(cur & 0xFFFFu) + 1;
+				p = cur;
+			}
+			if (prev != kCellNone && (int)(prev & 0xFFFFu) + 1 > v) {
+				v = (int)(prev & 0xFFFFu) + 1;
+				par = 1;
+				p = prev;
+			}
+			if (nxt != kCellNone && (int)(nxt & 0xFFFFu) > v) {
+				v = (int)(nxt & 0xFFFFu);
+				par = 2;
+				p = nxt;
+			}
+			int ii = v, jj = v - k;
+			const int ub = (2 * M - k < 2 * N + k ? 2 * M - k : 2 * N + k) - 6 * d;
+			uint32_t nc = kCellNone;
+			if (live && v >= 0 && ii <= M && jj <= N && jj >= 0 && ii + jj - 6 * d >= tcmp - kGX2 && ub > best) {
+				const int i_start = ii;
+				slide(ii, jj);
+				const uint32_t pk = (p >> 26) & 3u, pslid = (p >> 28) & 1u;
+				const uint32_t mism = ((p >> 16) & 31u) + (par == 0 ? 1u : 0u);
+				const uint32_t gopen = ((p >> 21) & 31u) + ((par != 0 && !(pk == (uint32_t)par && !pslid)) ? 1u : 0u);
+				nc = (uint32_t)ii | (mism << 16) | (gopen << 21) | ((uint32_t)par << 26) | (ii > i_start ? 1u << 28 : 0u);
+				const int s2 = ii + jj - 6 * d;
+				if (s2 > best) {
+					best = s2;
+					out.i = ii;
+					out.j = jj;
+					out.s2 = s2;
+					out.mism = (int)mism;
+					out.gopen = (int)gopen;
+				}
+				any = true;
+			}
+			const unsigned long long am = __ballot(nc != kCellNone);
+			if (am) {
+				nl = k < nl ? k : nl;
+				nu = k;
+			}
+			prev = cur;
+			R[c] = nc;
+		}
+		if (d == 1)
+			T1 = best;
+		else if (d == 2)
+			T2 = best;
+		else if (d == 3)
+			T3 = best;
+		else if (d == 4)
+			T4 = best;
+		live = live && any;
+		Lw = __builtin_amdgcn_readfirstlane(nl);
+		Uw = __builtin_amdgcn_readfirstlane(nu);
 	}
-	if (!done) {
-		const uint32_t slot = atomicAdd(big_count, 1u);
-		if (slot < big_cap)
-			big_list[slot] = (unsigned long long)(uintptr_t)hp;
-	}
+	return !over;
 }
 
-constexpr int kGWaves = 4;
+constexpr int kBlkItems = 2048; // HSPs a wavefront orders at a time
+constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of the seed run, capped at 15
 
-// main table: hits of read r are the read_cnt[r] records from read_start[r] (reads whose hits went to the overflow table
-// carry kFragmented); a wavefront takes 64 reads at a time and deals their hits to its lanes
-__global__ __launch_bounds__(64 * kGWaves) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
-							       const uint32_t *__restrict__ read_start,
-							       const uint32_t *__restrict__ read_cnt, uint32_t n_reads,
-							       unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count,
-							       uint32_t big_cap)
+template <int MAXL> struct FastLds {
+	static constexpr int kRd = MAXL / 16 + 2;                          // read strand, 16 bases per word
+	static constexpr int kDb = (MAXL + 2 * kGFastD + 48 + 15) / 16 + 1; // database window
+	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
+	uint32_t seq[64][kSeq];
+	uint32_t bucket[kKeyBuckets];
+	uint16_t order[kBlkItems];
+};
+
+// FLAT: the table is a flat array of *count hits (overflow table); otherwise the hits of read r are the read_cnt[r] records
+// from read_start[r] of the seed stage's main table (kFragmented: they are in the overflow table).
+// A wavefront takes the HSPs of 64 reads (at most kBlkItems at a time), orders them by the seed stage's work estimate
+// (a counting sort in LDS), and runs them 64 at a time: lanes of one round have about the same number of rows.
+template <bool FLAT, int MAXL>
+__global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
+						     const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
+						     uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
+						     unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
+						     uint2 *__restrict__ side_res)
 {
-	__shared__ uint32_t s_cells[kGWaves][64][kGFastCells];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	uint32_t *cells = s_cells[wave][lane];
-	for (uint32_t rb = (blockIdx.x * kGWaves + wave) * 64u; rb < n_reads; rb += gridDim.x * kGWaves * 64u) {
-		const uint32_t r = rb + lane;
-		uint32_t cnt = 0, st = 0;
-		if (r < n_reads) {
-			st = read_start[r];
-			cnt = st == kFragmented ? 0u : read_cnt[r];
-			if ((unsigned long long)st + cnt > table_cap)
-				cnt = 0; // the table was too small for this read: the host repeats the step with a larger one
-		}
-		uint32_t incl = cnt;
+	using Lds = FastLds<MAXL>;
+	__shared__ Lds lds;
+	const int lane = threadIdx.x & 63;
+	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
+	const unsigned long long n_flat = FLAT ? (*flat_count < table_cap ? *flat_count : table_cap) : 0ull;
+	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
+
+	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+		uint32_t excl = 0, st = 0, T;
+		if (FLAT) {
+			const unsigned long long left = n_flat - blk * kBlkItems;
+			T = (uint32_t)(left < (unsigned long long)kBlkItems ? left : (unsigned long long)kBlkItems);
+		} else {
+			const uint32_t r = (uint32_t)blk * 64u + lane;
+			uint32_t cnt = 0;
+			if (r < n_reads) {
+				st = read_start[r];
+				cnt = st == kFragmented ? 0u : read_cnt[r];
+				if ((unsigned long long)st + cnt > table_cap)
+					cnt = 0; // the table was too small for this read: the host repeats the step with a larger one
+			}
+			uint32_t incl = cnt;
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d);
-			if (lane >= d)
-				incl += t;
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint32_t t = __shfl_up(incl, dd);
+				if (lane >= dd)
+					incl += t;
+			}
+			excl = incl - cnt;
+			T = __shfl(incl, 63);
 		}
-		const uint32_t excl = incl - cnt, T = __shfl(incl, 63);
-		for (uint32_t it = 0; it < T; it += 64) {
-			const uint32_t item = it + lane;
-			const bool active = item < T;
-			const uint32_t key = active ? item : T - 1;
+		// item -> its record
+		auto locate = [&](uint32_t item) -> pgx_hit * {
+			if (FLAT)
+				return table + blk * kBlkItems + item;
 			int o = 0;
 #pragma unroll
 			for (int step = 32; step >= 1; step >>= 1) {
 				const int cand = o + step;
 				const uint32_t e = __shfl(excl, cand & 63);
-				if (cand < 64 && e <= key)
+				if (cand < 64 && e <= item)
 					o = cand;
 			}
 			const uint32_t base = __shfl(st, o), ex = __shfl(excl, o);
-			if (active)
-				gapped_one(v, table + base + (key - ex), cells, big_list, big_count, big_cap);
+			return table + base + (item - ex);
+		};
+		for (uint32_t chunk = 0; chunk < T; chunk += kBlkItems) {
+			const uint32_t n_it = T - chunk < (uint32_t)kBlkItems ? T - chunk : (uint32_t)kBlkItems;
+			// The two sides of an HSP cost differently (rows ~ 1.2 x the mismatches of the diagonal on that side), so they
+			// are run as separate passes, each ordered by its own side's estimate: side 0 = left of the anchor (its result is
+			// parked in `side_res`), side 1 = right of it (reads the parked result and writes the finished hit).
+			for (int side = 0; side < 2; side++) {
+				// ---- counting sort of the chunk's HSPs by the side's mismatch estimate (16 buckets)
+				if (lane < kKeyBuckets)
+					lds.bucket[lane] = 0;
+				lds_sync();
+				for (uint32_t it = 0; it < n_it; it += 64) {
+					const uint32_t item = it + lane;
+					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
+					if (item < n_it) {
+						const uint32_t mg = reinterpret_cast<const uint32_t *>(p)[7];
+						atomicAdd(&lds.bucket[(side ? mg >> 16 : mg) & 15u], 1u);
+					}
+				}
+				lds_sync();
+				{
+					const uint32_t c = lane < kKeyBuckets ? lds.bucket[lane] : 0u;
+					uint32_t incl = c;
+#pragma unroll
+					for (int dd = 1; dd < kKeyBuckets; dd <<= 1) {
+						const uint32_t t = __shfl_up(incl, dd);
+						if (lane >= dd)
+							incl += t;
+					}
+					if (lane < kKeyBuckets)
+						lds.bucket[lane] = incl - c;
+				}
+				lds_sync();
+				for (uint32_t it = 0; it < n_it; it += 64) {
+					const uint32_t item = it + lane;
+					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
+					if (item < n_it) {
+						const uint32_t mg = reinterpret_cast<const uint32_t *>(p)[7];
+						const uint32_t slot = atomicAdd(&lds.bucket[(side ? mg >> 16 : mg) & 15u], 1u);
+						lds.order[slot] = (uint16_t)item;
+					}
+				}
+				lds_sync();
+				// ---- 64 sides of similar cost per round
+				for (uint32_t it = 0; it < n_it; it += 64) {
+					const bool mine = it + lane < n_it;
+					const uint32_t item = lds.order[mine ? it + lane : n_it - 1];
+					pgx_hit *hp = locate(chunk + item);
+					const size_t slot = (size_t)(hp - table);
+					pgx_hit h;
+					h.read = h.subject = h.qstart = h.qend = h.sstart = h.send = h.score = 0;
+					h.mismatch = h.gapopen = 0;
+					Anchor a;
+					a.strand = a.L = a.qa = a.sa = a.slen = 0;
+					a.S0 = 0;
+					a.s.rw = a.s.ra = a.s.dbw = a.s.dba = nullptr;
+					bool on = false;
+					int win0 = 0;
+					uint2 parked = make_uint2(0u, 0u);
+					if (mine) {
+						h = *hp;
+						a = anchor_of(v, h);
+						// the database window of this HSP: from kGFastD + 16 bases left of where the read's first base
+						// would lie, in whole 16-base words
+						const int64_t lo = (a.S0 + a.sa - a.qa - kGFastD - 16) >> 4; // word index (may be negative: front padding)
+						bool wide = a.L > MAXL;
+						if (side == 1) {
+							parked = side_res[slot];
+							wide = (parked.y >> 31) != 0u; // the left pass sent this HSP to the wide kernel
+						} else {
+							if (!wide && a.s.ra) {
+								uint64_t any = 0;
+								for (int w = 0; w < (a.L + 31) / 32; w++)
+									any |= a.s.ra[w];
+								wide = any != 0;
+							}
+							if (!wide && a.s.dba) {
+								const int64_t b0 = (lo * 16) >> kBlkShift, b1 = (lo * 16 + Lds::kDb * 16) >> kBlkShift;
+								if (v.amb_blk) {
+									for (int64_t bb = b0 < 0 ? 0 : b0; bb <= b1; bb++)
+										wide = wide || ((v.amb_blk[bb >> 5] >> (bb & 31)) & 1u);
+								} else {
+									wide = true;
+								}
+							}
+						}
+						if (!wide) {
+							// this side's letters: read [0, qa) and the window left of the anchor, or the rest
+							const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw);
+							const int r0 = side ? a.qa >> 4 : 0, r1 = side ? Lds::kRd : (a.qa >> 4) + 2;
+							for (int w = r0; w < r1 && w < Lds::kRd; w++)
+								rdw[w] = gr[w];
+							const uint32_t *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
+							const int mid = (int)(((a.S0 + a.sa) >> 4) - lo); // window word that holds the anchor
+							const int d0w = side ? mid : 0, d1w = side ? Lds::kDb : mid + 2;
+							for (int w = d0w; w < d1w && w < Lds::kDb; w++)
+								dbwin[w] = gd[w];
+							win0 = (int)(lo * 16 - a.S0);
+							on = true;
+						}
+					}
+					lds_sync();
+					Side sd;
+					bool ok;
+					if (side == 0)
+						ok = greedy_rows(rdw, dbwin, on, -1, a.qa - 1, a.sa - 1 - win0, a.qa, a.sa, sd);
+					else
+						ok = greedy_rows(rdw, dbwin, on, +1, a.qa, a.sa - win0, a.L - a.qa, a.slen - a.sa, sd);
+					if (mine) {
+						if (side == 0) {
+							// parked: i | j << 10 | mismatches << 20 | gap openings << 25 ; gap columns | wide << 31
+							const uint32_t gaps = (uint32_t)((sd.i + sd.j - sd.s2) / 6 - sd.mism);
+							side_res[slot] = (on && ok) ? make_uint2((uint32_t)sd.i | ((uint32_t)sd.j << 10) | ((uint32_t)sd.mism << 20) | ((uint32_t)sd.gopen << 25), gaps)
+										    : make_uint2(0u, 1u << 31);
+						} else if (on && ok) {
+							Side l;
+							l.i = (int)(parked.x & 1023u);
+							l.j = (int)((parked.x >> 10) & 1023u);
+							l.mism = (int)((parked.x >> 20) & 31u);
+							l.gopen = (int)(parked.x >> 25);
+							l.s2 = l.i + l.j - 6 * (l.mism + (int)parked.y);
+							write_gapped(hp, h, a, l, sd);
+						} else {
+							const uint32_t w = atomicAdd(big_count, 1u);
+							if (w < big_cap)
+								big_list[w] = (unsigned long long)(uintptr_t)hp;
+						}
+					}
+					lds_sync();
+				}
+			}
 		}
 	}
-}
-
-// overflow table: flat
-__global__ __launch_bounds__(64 * kGWaves) void k_gapped_flat(GapView v, pgx_hit *__restrict__ table, const unsigned long long *__restrict__ count,
-							       unsigned long long cap, unsigned long long *__restrict__ big_list,
-							       uint32_t *__restrict__ big_count, uint32_t big_cap)
-{
-	__shared__ uint32_t s_cells[kGWaves][64][kGFastCells];
-	uint32_t *cells = s_cells[threadIdx.x >> 6][threadIdx.x & 63];
-	const unsigned long long n = *count < cap ? *count : cap;
-	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
-		gapped_one(v, table + i, cells, big_list, big_count, big_cap);
 }
 
 // ------------------------------------------------------------------------------------------ one wavefront per HSP
@@ -302,12 +498,6 @@ struct BigLds {
 	uint2 row[2][kBigCells];
 	int ring[kGLag + 1]; // best score with at most d differences, for the last kGLag + 1 values of d
 };
-
-__device__ __forceinline__ void lds_sync()
-{
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-}
 
 template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int q0, int64_t d0, int M, int N, Side &out)
 {
@@ -438,7 +628,7 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint32_t *read_start, const uint32_t *read_cnt,
 		 pgx_hit *ovf_table, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, GappedWork &gw, hipStream_t stream)
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream)
 {
 	GapView v;
 	v.fwd = rv.fwd;
@@ -450,20 +640,36 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	v.dbw = dv.words;
 	v.dba = dv.amb;
 	v.seq_off = dv.seq_off;
+	v.amb_blk = dv.amb ? dv.amb_blk : nullptr;
 	// HSPs the lane-per-HSP kernel passes on: a handful for sequencing reads, every one for long queries
 	const unsigned long long want = long_reads ? hit_cap + ovf_cap : (1ull << 20);
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
 	PGX_TRY(gw.big_count.ensure(1));
+	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
+	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
 	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
-	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 64 * kGWaves - 1) / (64 * kGWaves), 256ull * 16);
-	hipLaunchKernelGGL(k_gapped_fast, dim3(grid ? grid : 1), dim3(64 * kGWaves), 0, stream, v, main_table, hit_cap, read_start, read_cnt, n,
-			   gw.big_list.data(), gw.big_count.data(), cap);
-	hipLaunchKernelGGL(k_gapped_flat, dim3(256), dim3(64 * kGWaves), 0, stream, v, ovf_table, ovf_count, ovf_cap, gw.big_list.data(),
-			   gw.big_count.data(), cap);
-	hipLaunchKernelGGL(k_gapped_big, dim3(long_reads ? 256 * 8 : 256), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap);
+	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 32);
+	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy)
+#define PGX_GAPPED_LAUNCH(ML)                                                                                                                \
+	do {                                                                                                                                 \
+		hipLaunchKernelGGL((k_gapped_fast<false, ML>), dim3(grid ? grid : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
+				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
+				   gw.side_main.data());                                                                                        \
+		hipLaunchKernelGGL((k_gapped_fast<true, ML>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
+				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
+				   gw.big_count.data(), cap, gw.side_ovf.data());                                                              \
+	} while (0)
+	if (max_len <= 192)
+		PGX_GAPPED_LAUNCH(192);
+	else if (max_len <= 320)
+		PGX_GAPPED_LAUNCH(320);
+	else
+		PGX_GAPPED_LAUNCH(512);
+#undef PGX_GAPPED_LAUNCH
+	hipLaunchKernelGGL(k_gapped_big, dim3(256 * 8), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap);
 	PGX_HIP(hipGetLastError());
 	return 0;
 }

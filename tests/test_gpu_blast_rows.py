@@ -28,7 +28,8 @@ def test_product_and_oracle_score_columns_are_the_same_text(oracle_bin):
     lib.o_blast_format_bitscore.argtypes = [C.c_double, C.c_char_p]
     lib.o_blast_format_evalue.argtypes = [C.c_double, C.c_char_p]
     for db_len, db_nseq in ((10 ** 9, 666667), (531842, 373), (3 * 10 ** 9, 2 * 10 ** 6)):
-        st = _Stats(1.28, 0.46, 0.85, db_len, db_nseq)
+        st = _Stats()
+        lib.o_blast_stats_init(C.byref(st), C.c_int64(db_len), C.c_int64(db_nseq), 1)   # spec v2: the gapped search's statistics
         for qlen in (28, 56, 150, 513, 1400, 70000):
             for score in list(range(28, 200)) + [777, 1402, 5000, 5415, 69999]:
                 if score > qlen:

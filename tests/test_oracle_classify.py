@@ -91,7 +91,13 @@ def diag_hsps(q, s, d, W=28, X=10):
                 elif bestr - cur > X:
                     break
             mism = sum(1 for k in range(bl, br + 1) if not mm(k))
-            res.append((bl, br, (j - i) + best + bestr, mism, i))
+            # S3b anchor: first base of the run of matches that holds the last matching position at or before the middle
+            anchor = bl + (br - bl) // 2
+            while not mm(anchor):
+                anchor -= 1
+            while anchor > bl and mm(anchor - 1):
+                anchor -= 1
+            res.append((bl, br, (j - i) + best + bestr, mism, anchor))
             covered = br + 1
         i = j
     return res
