@@ -252,6 +252,11 @@ int pgx_consensus_batch(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *r
  * `out` may be NULL (bench) */
 int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx_hits **hits_out,
 			   pgx_consensus_rec *out, int64_t cap);
+/* the same with the third classifier stream of `Consensus_BLAST_SOAP_RDP-1.1.pl -s` (BASELINE config 5): the SOAP table
+ * must be openable (PGX_E_IO with the script's message otherwise) and is otherwise ignored, as in the reference
+ * (Consensus:40-46); NULL, "" and "0" mean "not given" (Perl truth) */
+int pgx_classify_consensus_tri(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, const char *soap_stream_path,
+			       pgx_hits **hits_out, pgx_consensus_rec *out, int64_t cap);
 /* consensus text ("<hit line with lineage>\n#Matches found: N\n" per read), malloc'd */
 int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
 			 const pgx_consensus_rec *recs, int64_t n, char **text, size_t *len);

@@ -93,7 +93,7 @@ SYMBOLS = [
     "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
-    "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus",
+    "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri",
     "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather",
 ]
 
@@ -126,6 +126,7 @@ def _declare(L):
     sig("pgx_rdp_from_synth", C.c_int, [V, I64, I64, V, V])
     sig("pgx_consensus_batch", C.c_int, [V, V, V, V, I64])
     sig("pgx_classify_consensus", C.c_int, [V, V, V, V, V, I64])
+    sig("pgx_classify_consensus_tri", C.c_int, [V, V, V, C.c_char_p, V, V, I64])
     sig("pgx_consensus_format", C.c_int, [V, V, V, V, I64, V, V])
     sig("pgx_tax_lineage_batch", C.c_int, [V, V, I64, V, V, V])
     sig("pgx_megaclust_file", C.c_int, [V, V])
@@ -396,12 +397,17 @@ def blast_search(db, reads):
     return Hits(p)
 
 
-def classify_consensus(db, reads, rdp, want_records=True, want_hits=True):
+def classify_consensus(db, reads, rdp, want_records=True, want_hits=True, soap=None):
+    """The fused hot path; `soap` = path of the SOAP classification (the -s stream of the reference's Consensus)."""
     n = len(reads)
     recs = np.zeros(n, dtype=REC_DTYPE) if want_records else None
     hp = C.c_void_p()
-    _check(lib().pgx_classify_consensus(db.ptr, reads.ptr, rdp.ptr, C.byref(hp) if want_hits else None,
-                                        recs.ctypes.data if want_records else None, n))
+    if soap is None:
+        _check(lib().pgx_classify_consensus(db.ptr, reads.ptr, rdp.ptr, C.byref(hp) if want_hits else None,
+                                            recs.ctypes.data if want_records else None, n))
+    else:
+        _check(lib().pgx_classify_consensus_tri(db.ptr, reads.ptr, rdp.ptr, _b(soap), C.byref(hp) if want_hits else None,
+                                                recs.ctypes.data if want_records else None, n))
     return (Hits(hp) if want_hits else None), recs
 
 

@@ -2057,6 +2057,21 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 	return rc;
 }
 
+// BASELINE config 5 (BLAST + SOAP + RDP): the reference's Consensus takes the SOAP classification as a third stream,
+// opens it, and never reads it (Consensus_BLAST_SOAP_RDP-1.1.pl:40-46; an option value that Perl holds false -- "" or
+// "0" -- counts as not given).  Same here: the stream must be openable, and the records do not depend on it.
+int pgx_classify_consensus_tri(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, const char *soap_stream_path, pgx_hits **hits_out,
+			       pgx_consensus_rec *out, int64_t cap)
+{
+	if (soap_stream_path && *soap_stream_path && strcmp(soap_stream_path, "0") != 0) {
+		FILE *f = fopen(soap_stream_path, "r");
+		if (!f)
+			return fail(PGX_E_IO, "Error: Unable to open %s file.", soap_stream_path);
+		fclose(f);
+	}
+	return pgx_classify_consensus(db, reads, rdp, hits_out, out, cap);
+}
+
 int pgx_db_set_ungapped(pgx_db *db, int ungapped)
 {
 	if (!db)
