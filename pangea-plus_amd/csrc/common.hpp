@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,20 @@ int require_device();
 		if (rc_ < 0)                                                                       \
 			return rc_;                                                                \
 	} while (0)
+
+// No C++ exception crosses the C ABI: an entry point whose body sizes containers from its input runs inside guard()
+template <typename F> int guard(const char *what, F &&body)
+{
+	try {
+		return body();
+	} catch (const std::bad_alloc &) {
+		return fail(PGX_E_NOMEM, "%s: out of host memory", what);
+	} catch (const std::length_error &) {
+		return fail(PGX_E_FORMAT, "%s: a size in the input is not plausible", what);
+	} catch (const std::exception &e) {
+		return fail(PGX_E_FORMAT, "%s: %s", what, e.what());
+	}
+}
 
 // Owning device allocation. `front_pad` elements are kept in front of data() so that kernels
 // may read a little before the first element (diagonals that start left of the database).

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <chrono>
 
+#include <sys/stat.h>
+
 #include "bitops.hpp"
 #include "engine.hpp"
 #include "textops.hpp"
@@ -638,6 +640,17 @@ static int db_read_file(const char *prefix, pgx_db **out)
 	if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, sizeof hdr, 1, f) != 1) {
 		fclose(f);
 		return fail(PGX_E_FORMAT, "%s is not a pgxdb file", path.c_str());
+	}
+	// the header is checked against the file before anything is sized by it (a damaged file used to end in bad_alloc)
+	struct stat sb;
+	const bool have_size = fstat(fileno(f), &sb) == 0;
+	const int64_t n_seq = hdr[0], n_bases = hdr[1], n_words = hdr[3];
+	const bool sane = n_seq >= 0 && n_bases >= 0 && n_bases < (1ll << 32) - 64 && n_seq <= n_bases + 1 && n_words == (n_bases + 31) / 32 &&
+			  (!have_size || (int64_t)sb.st_size >= 40 + 4 * (n_seq + 1) + 8 * n_words * (hdr[2] ? 2 : 1) + 4 * n_seq);
+	if (!sane) {
+		fclose(f);
+		return fail(PGX_E_FORMAT, "%s: header does not fit the file (%lld sequences, %lld bases, %lld words)", path.c_str(),
+			    (long long)n_seq, (long long)n_bases, (long long)n_words);
 	}
 	pgx_db *db = new pgx_db();
 	db->n_seq = hdr[0];
@@ -1432,15 +1445,17 @@ int pgx_db_open(const char *prefix, pgx_db **out)
 	if (!prefix || !out)
 		return fail(PGX_E_ARG, "pgx_db_open: null argument");
 	PGX_TRY(require_device());
-	pgx_db *db = nullptr;
-	PGX_TRY(db_read_file(prefix, &db));
-	int rc = db_upload_and_index(db);
-	if (rc < 0) {
-		delete db;
-		return rc;
-	}
-	*out = db;
-	return 0;
+	return pgx::guard("pgx_db_open", [&]() -> int {
+		pgx_db *db = nullptr;
+		PGX_TRY(db_read_file(prefix, &db));
+		int rc = db_upload_and_index(db);
+		if (rc < 0) {
+			delete db;
+			return rc;
+		}
+		*out = db;
+		return 0;
+	});
 }
 
 int pgx_db_from_fasta(const char *fasta_path, pgx_db **out)

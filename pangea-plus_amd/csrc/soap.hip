@@ -246,7 +246,11 @@ static void soap_row(std::string &out, const std::string &name, const std::vecto
 	out += '\t';
 	out.append((size_t)L, 'h');
 	char buf[256];
-	snprintf(buf, sizeof buf, "\t%u\ta\t%d\t%c\t%s\t%u\t%d", nbest, L, strand ? '-' : '+', db->ids[h.subject].c_str(), h.pos + 1, nmis);
+	// (the subject id is appended as it is: ids are accepted up to 1 MiB, a fixed buffer would cut the row)
+	snprintf(buf, sizeof buf, "\t%u\ta\t%d\t%c\t", nbest, L, strand ? '-' : '+');
+	out += buf;
+	out += db->ids[h.subject];
+	snprintf(buf, sizeof buf, "\t%u\t%d", h.pos + 1, nmis);
 	out += buf;
 	const uint64_t g0 = (uint64_t)db->h_seq_off[h.subject] + h.pos;
 	int m[2] = { h.mis0, h.mis1 };

@@ -90,3 +90,33 @@ def test_fasta_is_split_on_the_device_like_the_host_rules(tmp_path):
     rows = hits.format(db, reads).decode().splitlines()
     names_hit = {r.split("\t")[0] for r in rows}
     assert names_hit <= {n_ for n_, _ in recs}
+
+
+def test_damaged_database_file_and_bad_rank_are_errors_not_crashes(tmp_path):
+    """A .pgxdb whose header does not fit the file returns PGX_E_FORMAT (it used to end in std::bad_alloc across the C ABI),
+    and `blastn -rank` outside [0, world_size) is refused instead of writing an empty table."""
+    import struct
+    import pangea_plus_amd as pg
+    from pangea_plus_amd import _capi
+    pg.init(0)
+    fa = tmp_path / "d.fa"
+    fa.write_text(">gi|1|x|a|\n" + "ACGT" * 100 + "\n>gi|2|x|b|\n" + "GATTACA" * 40 + "\n")
+    pg.makeblastdb(str(fa), str(tmp_path / "d"))
+    good = (tmp_path / "d.pgxdb").read_bytes()
+    pg.Db.open(str(tmp_path / "d")).close()
+    for field, value in ((0, -5), (0, 1 << 40), (1, -1), (1, 1 << 50), (3, 1 << 45), (3, 0)):
+        hdr = list(struct.unpack("<4q", good[8:40]))
+        hdr[field] = value
+        (tmp_path / "bad.pgxdb").write_bytes(good[:8] + struct.pack("<4q", *hdr) + good[40:])
+        with pytest.raises(_capi.PangeaError) as e:
+            pg.Db.open(str(tmp_path / "bad"))
+        assert e.value.status == -4, (field, value)
+    (tmp_path / "bad.pgxdb").write_bytes(good[:60])
+    with pytest.raises(_capi.PangeaError):
+        pg.Db.open(str(tmp_path / "bad"))
+    q = tmp_path / "q.fa"
+    q.write_text(">r\n" + "ACGT" * 40 + "\n")
+    for rk, ws in ((2, 2), (-1, 2), (5, 3)):
+        with pytest.raises(_capi.PangeaError) as e:
+            pg.blastn(str(q), str(tmp_path / "d"), str(tmp_path / "o.tsv"), rank=rk, world_size=ws)
+        assert e.value.status == -1
