@@ -27,11 +27,12 @@ namespace pgx {
 
 constexpr int kGX2 = 108;     // 2 X
 constexpr int kGLag = 19;     // floor((X + 1/2) / 3) + 1: the X-drop test looks at the best score 19 differences earlier
-constexpr int kGFastD = 23;   // differences per side of the lane-per-HSP kernel (99.997 % of the sides of 150-base reads at 6 % divergence)
+constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel: below kGLag, so it never makes an X-drop test
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
-constexpr uint32_t kCellNone = 0xFFFFFFFFu;
-static_assert(kGFastD - kGLag <= 4, "the lane-per-HSP kernel keeps the best scores of the first five rows");
+constexpr uint32_t kCellNone = 0x00008000u; // lane kernel: a dead cell holds i = -32768
+constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
+static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
 
 __device__ __forceinline__ void lds_sync()
 {
@@ -175,10 +176,19 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 
 // One side of a lane's HSP, all 64 lanes in step: the loops over d and k are wave-uniform, so the row R(d, .) of a lane
 // lives in REGISTERS (kGFastCells words, indexed by the unrolled k) and is updated in place, k ascending.  Lanes whose
-// cell is dead, or that have finished, idle for that step; the caller groups HSPs of similar cost to keep that rare.
-// cell: bits 0-15 i, 16-20 mismatches, 21-25 gap openings, 26-27 kind of the last difference (0 mismatch, 1 gap in the
-// subject row, 2 gap in the query row), 28: letters matched after it.
+// cell is dead, or that have finished, idle for that step; the caller groups sides of similar cost to keep that rare.
+// cell: bits 0-15 i (signed; kCellNone holds -32768 there, so a dead parent loses every max), 16-20 mismatches, 21-25 gap
+// openings, 26-27 kind of the last difference (0 mismatch, 1 gap in the subject row, 2 gap in the query row), 28: letters
+// matched after it.
+//
+// A second cut, also unable to change the result while no X-drop test is made (d < kGLag: every score then passes it):
+// B0 = the best score of the path that never leaves the anchor's diagonal, found first with a walk over its mismatches.
+// That path is among the cells of the literal algorithm, so the final best is >= B0; a cell whose bound is BELOW B0 can
+// neither reach the final best nor tie it, its children's bounds are lower still, and no surviving cell has such a
+// parent.  A side that is still alive at d = kGLag goes to the wide kernel, which makes the X-drop tests.
 // Returns false for a lane whose cells are still alive after kGFastD differences.
+__device__ __forceinline__ int sext16(uint32_t c) { return (int)(int16_t)(uint16_t)c; }
+
 __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int dir, int q0, int d0, int M, int N,
 					     Side &out)
 {
@@ -202,14 +212,36 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	out.i = out.j = i0;
 	out.s2 = 2 * i0;
 	bool live = on && !(i0 == M || i0 == N); // this lane still has cells to explore
+	// B0: the anchor's diagonal alone (mismatch, slide, mismatch, ...), as far as both sequences go
+	int b0 = 2 * i0;
+	{
+		int wi = i0, wd = 0;
+		bool walking = live;
+		while (__ballot(walking) != 0ull) {
+			if (walking) {
+				wd++;
+				wi++;
+				int wj = wi;
+				if (wi > M || wi > N || wd >= kGLag) {
+					walking = false;
+				} else {
+					slide(wi, wj);
+					const int s2 = 2 * wi - 6 * wd;
+					b0 = s2 > b0 ? s2 : b0;
+					if (wi == M || wi == N)
+						walking = false;
+				}
+			}
+		}
+	}
 	uint32_t R[kGFastCells];
 #pragma unroll
 	for (int c = 0; c < kGFastCells; c++)
 		R[c] = kCellNone;
 	constexpr int C = kGFastD + 1;
-	R[C] = live ? ((uint32_t)i0 | (i0 > 0 ? 1u << 28 : 0u)) : kCellNone;
+	R[C] = live ? (((uint32_t)i0 & 0xFFFFu) | (i0 > 0 ? 1u << 28 : 0u)) : kCellNone;
 	int best = 2 * i0;
-	int T0 = best, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+	const int A2 = 2 * M, B2 = 2 * N;
 	int Lw = 0, Uw = 0; // wave-wide range of diagonals that hold a live cell
 	bool over = false;
 	for (int d = 1; __ballot(live) != 0ull; d++) {
@@ -217,44 +249,34 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			over = live;
 			break;
 		}
-		const int td = d - kGLag;
-		const int tcmp = td < 0 ? 0 : (td == 0 ? T0 : td == 1 ? T1 : td == 2 ? T2 : td == 3 ? T3 : T4);
 		uint32_t prev = kCellNone; // the old value of the cell left of the one being written
 		bool any = false;
 		int nl = 1 << 20, nu = -(1 << 20);
+		const int six_d = 6 * d;
 #pragma unroll
 		for (int c = 1; c < kGFastCells - 1; c++) {
 			const int k = c - C;
 			if (k < Lw - 1 || k > Uw + 1) // wave-uniform: no lane has a parent for this diagonal
 				continue;
 			const uint32_t cur = R[c], nxt = R[c + 1];
-			int v = -1, par = 0;
-			uint32_t p = 0;
-			if (cur != kCellNone) {
-				v = (int)(cur & 0xFFFFu) + 1;
-				p = cur;
-			}
-			if (prev != kCellNone && (int)(prev & 0xFFFFu) + 1 > v) {
-				v = (int)(prev & 0xFFFFu) + 1;
-				par = 1;
-				p = prev;
-			}
-			if (nxt != kCellNone && (int)(nxt & 0xFFFFu) > v) {
-				v = (int)(nxt & 0xFFFFu);
-				par = 2;
-				p = nxt;
-			}
-			int ii = v, jj = v - k;
-			const int ub = (2 * M - k < 2 * N + k ? 2 * M - k : 2 * N + k) - 6 * d;
+			// the three parents without a branch: a mismatch on this diagonal wins ties, then diagonal k - 1, then k + 1
+			const int vc = sext16(cur) + 1, vp = sext16(prev) + 1, vn = sext16(nxt);
+			const int v = max(vc, max(vp, vn));
+			const bool from_c = (vc >= vp) & (vc >= vn), from_p = !from_c & (vp >= vn);
+			const uint32_t p = from_c ? cur : (from_p ? prev : nxt);
+			const uint32_t par = from_c ? 0u : (from_p ? 1u : 2u);
+			const int jj0 = v - k;
+			const int ub = min(A2 - k, B2 + k) - six_d;
+			const bool alive = live & (v >= 0) & (v <= M) & (jj0 <= N) & (jj0 >= 0) & (ub > best) & (ub >= b0);
 			uint32_t nc = kCellNone;
-			if (live && v >= 0 && ii <= M && jj <= N && jj >= 0 && ii + jj - 6 * d >= tcmp - kGX2 && ub > best) {
-				const int i_start = ii;
+			if (alive) {
+				int ii = v, jj = jj0;
 				slide(ii, jj);
 				const uint32_t pk = (p >> 26) & 3u, pslid = (p >> 28) & 1u;
-				const uint32_t mism = ((p >> 16) & 31u) + (par == 0 ? 1u : 0u);
-				const uint32_t gopen = ((p >> 21) & 31u) + ((par != 0 && !(pk == (uint32_t)par && !pslid)) ? 1u : 0u);
-				nc = (uint32_t)ii | (mism << 16) | (gopen << 21) | ((uint32_t)par << 26) | (ii > i_start ? 1u << 28 : 0u);
-				const int s2 = ii + jj - 6 * d;
+				const uint32_t mism = ((p >> 16) & 31u) + (par == 0u ? 1u : 0u);
+				const uint32_t gopen = ((p >> 21) & 31u) + (((par != 0u) & !((pk == par) & (pslid == 0u))) ? 1u : 0u);
+				nc = ((uint32_t)ii & 0xFFFFu) | (mism << 16) | (gopen << 21) | (par << 26) | (ii > v ? 1u << 28 : 0u);
+				const int s2 = ii + jj - six_d;
 				if (s2 > best) {
 					best = s2;
 					out.i = ii;
@@ -265,22 +287,13 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				}
 				any = true;
 			}
-			const unsigned long long am = __ballot(nc != kCellNone);
-			if (am) {
+			if (__ballot(alive) != 0ull) {
 				nl = k < nl ? k : nl;
 				nu = k;
 			}
 			prev = cur;
 			R[c] = nc;
 		}
-		if (d == 1)
-			T1 = best;
-		else if (d == 2)
-			T2 = best;
-		else if (d == 3)
-			T3 = best;
-		else if (d == 4)
-			T4 = best;
 		live = live && any;
 		Lw = __builtin_amdgcn_readfirstlane(nl);
 		Uw = __builtin_amdgcn_readfirstlane(nu);
@@ -298,6 +311,8 @@ template <int MAXL> struct FastLds {
 	uint32_t seq[64][kSeq];
 	uint32_t bucket[kKeyBuckets];
 	uint16_t order[kBlkItems];
+	// (no copy of the work keys: 2 KB more LDS costs a wavefront per SIMD, and the rows are bound by vector issue:
+	// 12.6 KB -> 14.7 KB per wavefront ran 24 -> 31 ms per 2 M reads; 1 024-HSP chunks fill the buckets too thinly: 31 ms)
 };
 
 // FLAT: the table is a flat array of *count hits (overflow table); otherwise the hits of read r are the read_cnt[r] records
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 						     const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
 						     uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
 						     unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
-						     uint2 *__restrict__ side_res)
+						     uint2 *__restrict__ side_res, int dbg)
 {
 	using Lds = FastLds<MAXL>;
 	__shared__ Lds lds;
@@ -460,6 +475,12 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 					lds_sync();
 					Side sd;
 					bool ok;
+					if (dbg == 2)
+						on = false; // (probe: everything but the rows)
+					if (dbg == 1) {
+						lds_sync();
+						continue; // (probe: ordering + staging only)
+					}
 					if (side == 0)
 						ok = greedy_rows(rdw, dbwin, on, -1, a.qa - 1, a.sa - 1 - win0, a.qa, a.sa, sd);
 					else
@@ -529,12 +550,12 @@ template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int
 			const int k = kb + lane;
 			const bool in = k <= U + 1;
 			// rows are read through [L, U] only, and every cell of [L - 1, U + 1] is written each round (dead ones
-			// as kCellNone), so no stale cell of an earlier round is ever read
+			// as kBigNone), so no stale cell of an earlier round is ever read
 			auto old = [&](int kk, uint2 &c) {
 				bool ok = kk >= L && kk <= U;
 				if (ok) {
 					c = pa[C + kk];
-					ok = c.x != kCellNone;
+					ok = c.x != kBigNone;
 				}
 				return ok;
 			};
@@ -571,7 +592,7 @@ template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int
 				s2 = ii + jj - 6 * d;
 			}
 			if (in)
-				pb[C + k] = alive ? make_uint2((uint32_t)ii, stats) : make_uint2(kCellNone, 0u);
+				pb[C + k] = alive ? make_uint2((uint32_t)ii, stats) : make_uint2(kBigNone, 0u);
 			const unsigned long long am = __ballot(alive);
 			if (am) {
 				const int lo = __ffsll((unsigned long long)am) - 1, hi = 63 - __clzll((long long)am);
@@ -652,15 +673,16 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 32);
+	const int dbg = getenv("PGX_GAP_DBG") ? atoi(getenv("PGX_GAP_DBG")) : 0; // (measurement aid)
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy)
 #define PGX_GAPPED_LAUNCH(ML)                                                                                                                \
 	do {                                                                                                                                 \
 		hipLaunchKernelGGL((k_gapped_fast<false, ML>), dim3(grid ? grid : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
-				   gw.side_main.data());                                                                                        \
+				   gw.side_main.data(), dbg);                                                                                        \
 		hipLaunchKernelGGL((k_gapped_fast<true, ML>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
 				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
-				   gw.big_count.data(), cap, gw.side_ovf.data());                                                              \
+				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg);                                                              \
 	} while (0)
 	if (max_len <= 192)
 		PGX_GAPPED_LAUNCH(192);
