@@ -35,7 +35,9 @@
 #define G_DMAX 1000
 #define G_NONE (-0x3FFFFFFF)
 
-/* exploration statistics (single-threaded runs only): sides by last difference count explored, cells evaluated */
+/* exploration statistics, when o_greedy_stats is set (single-threaded runs only): sides by last difference count
+ * explored, cells evaluated */
+int o_greedy_stats = 0;
 long long o_greedy_depth_hist[64], o_greedy_cells;
 
 static inline int g_match(uint8_t a, uint8_t b)
@@ -53,7 +55,8 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 	out->i = out->j = i;
 	out->s2 = 2 * i;
 	if (i == M || i == N) {
-		o_greedy_depth_hist[0]++;
+		if (o_greedy_stats)
+			o_greedy_depth_hist[0]++;
 		return; /* a sequence end: every further cell only loses */
 	}
 	const int32_t dcap = G_DMAX;
@@ -98,7 +101,8 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 				if (ub <= best)
 					dead = 1;
 			}
-			o_greedy_cells += !dead;
+			if (o_greedy_stats)
+				o_greedy_cells += !dead;
 			if (dead) {
 				RC(k) = G_NONE;
 				mv[d][k + d] = 0;
@@ -131,7 +135,8 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 		L = nl;
 		U = nu;
 	}
-	o_greedy_depth_hist[d < 63 ? d : 63]++;
+	if (o_greedy_stats)
+		o_greedy_depth_hist[d < 63 ? d : 63]++;
 	/* traceback from the best cell: the moves of the path (bits 0-1 kind, bit 2: the cell slid over matches after it) */
 	out->i = best_i;
 	out->j = best_i - best_k;
