@@ -196,6 +196,8 @@ int pgx_reads_from_fasta(const char *path, int64_t first, int64_t count, pgx_rea
  * output_files/trim2/..._runblast.fasta file in between (README.md:34 -> :96) */
 int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64_t count, pgx_reads **out);
 int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, pgx_reads **out);
+/* the batch back as FASTA text (">name", one sequence line): the file trim2 hands to blastn (README.md:34 -> :96) */
+int pgx_reads_write_fasta(const pgx_reads *r, const char *path);
 void pgx_reads_close(pgx_reads *r);
 int64_t pgx_reads_count(const pgx_reads *r);
 /* packed bases of read i (2 bits per base, 32 per word, low bits first) for parity checks */
@@ -239,6 +241,8 @@ const char *pgx_db_subject_lineage(const pgx_db *db, int64_t subject);
 typedef struct pgx_rdp pgx_rdp;
 int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *db, pgx_rdp **out);
 int pgx_rdp_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, const pgx_db *db, pgx_rdp **out);
+/* the assignments of a batch as the classifier's five-tab text (Consensus:126-132); pgx_rdp_from_file reads it back */
+int pgx_rdp_write_file(const pgx_rdp *rdp, const pgx_reads *reads, const pgx_db *db, const char *path);
 void pgx_rdp_close(pgx_rdp *r);
 
 typedef struct {

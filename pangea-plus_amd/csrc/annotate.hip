@@ -15,6 +15,7 @@
 
 #include "bitops.hpp"
 #include "consensus_core.hpp"
+#include <mutex>
 #include <thread>
 
 #include "engine.hpp"
@@ -605,6 +606,55 @@ const char *pgx_db_subject_lineage(const pgx_db *db, int64_t subject)
 
 void pgx_rdp_close(pgx_rdp *r) { delete r; }
 
+// The RDP assignments of a batch as the classifier's text (Consensus:126-132: id, five tabs, then name / rank /
+// confidence in threes).  Reading the file back with pgx_rdp_from_file gives the same assignments.
+int pgx_rdp_write_file(const pgx_rdp *rdp, const pgx_reads *reads, const pgx_db *db, const char *path)
+{
+	if (!rdp || !reads || !db || !path || rdp->n != reads->n)
+		return fail(PGX_E_ARG, "pgx_rdp_write_file: bad argument");
+	return pgx::guard("pgx_rdp_write_file", [&]() -> int {
+		const size_t n = (size_t)rdp->n;
+		std::vector<uint32_t> off(n + 1);
+		PGX_TRY(rdp->d_off.download(off.data(), n + 1));
+		std::vector<uint32_t> name(off[n] ? off[n] : 1);
+		std::vector<int8_t> rank(off[n] ? off[n] : 1);
+		std::vector<uint8_t> present(n ? n : 1);
+		PGX_TRY(rdp->d_name.download(name.data(), off[n]));
+		PGX_TRY(rdp->d_rank.download(rank.data(), off[n]));
+		PGX_TRY(rdp->d_present.download(present.data(), n));
+		static const char *const kRank[7] = { "domain", "phylum", "class", "order", "family", "genus", "species" };
+		FILE *f = fopen(path, "wb");
+		if (!f)
+			return fail(PGX_E_IO, "cannot open %s for writing", path);
+		std::string out;
+		out.reserve(64u << 20);
+		bool ok = true;
+		for (size_t r = 0; r < n && ok; r++) {
+			if (!present[r])
+				continue;
+			out += reads->name_of((int64_t)r);
+			out += "\t\t\t\t\t";
+			for (uint32_t t = off[r]; t < off[r + 1]; t++) {
+				if (t > off[r])
+					out += '\t';
+				out += name[t] < db->token_text.size() ? db->token_text[name[t]] : std::string();
+				out += '\t';
+				out += rank[t] >= 0 && rank[t] < 7 ? kRank[rank[t]] : "norank";
+				out += "\t0.90";
+			}
+			out += '\n';
+			if (out.size() > (60u << 20)) {
+				ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+				out.clear();
+			}
+		}
+		ok = ok && fwrite(out.data(), 1, out.size(), f) == out.size();
+		if (fclose(f) != 0 || !ok)
+			return fail(PGX_E_IO, "short write to %s", path);
+		return 0;
+	});
+}
+
 int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cdb, pgx_rdp **out)
 {
 	pgx_db *db = const_cast<pgx_db *>(cdb);
@@ -626,7 +676,67 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	// order; names may repeat).  The reads are indexed by name hash so that a line of a read that is not in this
 	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.
 	const ReadNameIndex index(*reads);
-	// the few distinct name / rank texts of an RDP file are cleaned and interned once each
+	static const char kFive[] = "\t\t\t\t\t";
+	const char *base = text.data();
+	// ---- lines
+	std::vector<size_t> ls; // start of every line, plus the end of the text
+	ls.reserve(text.size() / 64 + 2);
+	for (size_t s0 = 0; s0 < text.size();) {
+		ls.push_back(s0);
+		const char *nl = (const char *)memchr(base + s0, '\n', text.size() - s0);
+		s0 = nl ? (size_t)(nl - base) + 1 : text.size();
+	}
+	const size_t n_lines = ls.size();
+	ls.push_back(text.size() + (text.empty() || text.back() != '\n' ? 1 : 0)); // (line i ends one byte before the next start)
+	auto line_of = [&](size_t i, const char **line, size_t *len) {
+		*line = base + ls[i];
+		const size_t e = i + 1 < n_lines ? ls[i + 1] - 1 : (text.size() && text.back() == '\n' ? text.size() - 1 : text.size());
+		*len = e - ls[i];
+	};
+	const unsigned hw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_lines / 4096 + 1));
+	auto parallel = [&](const std::function<void(unsigned, size_t, size_t)> &f) {
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < hw; t++)
+			th.emplace_back(f, t, n_lines * t / hw, n_lines * (t + 1) / hw);
+		for (auto &x : th)
+			x.join();
+	};
+	// ---- pass 1 (all host cores): the read each line names.  With names that do not repeat inside the batch the cursor
+	// rule "first read at or after the cursor" is "the one read of that name, if it is not behind the cursor": a probe per
+	// line, independent of the others; batches with repeated names keep the sequential walk.
+	std::vector<uint32_t> line_read(n_lines, (uint32_t)n);
+	std::vector<uint32_t> id_len(n_lines, 0);
+	std::vector<uint8_t> has_five(n_lines, 0);
+	parallel([&](unsigned, size_t i0, size_t i1) {
+		for (size_t i = i0; i < i1; i++) {
+			const char *line;
+			size_t len;
+			line_of(i, &line, &len);
+			const char *five = (const char *)memmem(line, len, kFive, 5);
+			id_len[i] = (uint32_t)(five ? (size_t)(five - line) : len);
+			has_five[i] = five != nullptr;
+			if (index.unique)
+				line_read[i] = (uint32_t)index.find(line, id_len[i], 0);
+		}
+	});
+	{
+		size_t cursor = 0;
+		for (size_t i = 0; i < n_lines; i++) {
+			size_t r = line_read[i];
+			if (!index.unique)
+				r = index.find(base + ls[i], id_len[i], cursor);
+			else if (r < cursor)
+				r = n; // its only read lies behind the cursor
+			line_read[i] = (uint32_t)r;
+			if (r < n) {
+				cursor = r + 1;
+				present[r] = 1;
+			}
+		}
+	}
+	// ---- pass 2 (all host cores): the (name, rank, confidence) fields of the lines that belong to a read.  The few
+	// distinct name / rank texts of an RDP file are cleaned and interned once each (per thread; the database's token table
+	// behind a lock)
 	struct Memo {
 		std::unordered_map<uint64_t, std::vector<std::pair<std::string, uint32_t>>> m;
 		uint32_t get(const char *p, size_t len, const std::function<uint32_t(const std::string &)> &make)
@@ -638,49 +748,54 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			v.emplace_back(std::string(p, len), make(std::string(p, len)));
 			return v.back().second;
 		}
-	} names, ranks;
-	static const char kFive[] = "\t\t\t\t\t";
-	size_t cursor = 0;
-	const char *base = text.data();
-	for (size_t s = 0; s < text.size();) {
-		const char *nl = (const char *)memchr(base + s, '\n', text.size() - s);
-		const size_t e = nl ? (size_t)(nl - base) : text.size();
-		const char *line = base + s;
-		const size_t len = e - s;
-		s = e + 1;
-		const char *five = (const char *)memmem(line, len, kFive, 5);
-		const size_t id_len = five ? (size_t)(five - line) : len;
-		const size_t r = index.find(line, id_len, cursor);
-		if (r >= n)
-			continue; // an RDP line for a read that is not in this batch
-		cursor = r + 1;
-		present[r] = 1;
-		if (!five)
-			continue;
-		const char *rest = five + 5;
-		size_t rest_len = len - id_len - 5;
-		if (const char *again = (const char *)memmem(rest, rest_len, kFive, 5))
-			rest_len = (size_t)(again - rest);
-		while (rest_len && rest[rest_len - 1] == '\t') // trailing empty fields are dropped
-			rest_len--;
-		// fields in threes: name, rank, confidence
-		size_t a = 0;
-		for (int k = 0; a <= rest_len && (rest_len || k == 0); k++) {
-			const char *t = (const char *)memchr(rest + a, '\t', rest_len - a);
-			const size_t fe = t ? (size_t)(t - rest) : rest_len;
-			if (k % 3 == 0) {
-				if (rest_len == 0)
+	};
+	std::mutex intern_mu;
+	std::vector<std::vector<uint32_t>> t_name(hw);
+	std::vector<std::vector<int8_t>> t_rank(hw);
+	parallel([&](unsigned t, size_t i0, size_t i1) {
+		Memo names, ranks;
+		std::vector<uint32_t> &nm = t_name[t];
+		std::vector<int8_t> &rk = t_rank[t];
+		for (size_t i = i0; i < i1; i++) {
+			const size_t r = line_read[i];
+			if (r >= n || !has_five[i])
+				continue;
+			const char *line;
+			size_t len;
+			line_of(i, &line, &len);
+			const char *rest = line + id_len[i] + 5;
+			size_t rest_len = len - id_len[i] - 5;
+			if (const char *again = (const char *)memmem(rest, rest_len, kFive, 5))
+				rest_len = (size_t)(again - rest);
+			while (rest_len && rest[rest_len - 1] == '\t') // trailing empty fields are dropped
+				rest_len--;
+			// fields in threes: name, rank, confidence
+			size_t a = 0;
+			for (int k = 0; a <= rest_len && (rest_len || k == 0); k++) {
+				const char *tb = (const char *)memchr(rest + a, '\t', rest_len - a);
+				const size_t fe = tb ? (size_t)(tb - rest) : rest_len;
+				if (k % 3 == 0) {
+					if (rest_len == 0)
+						break;
+					nm.push_back(names.get(rest + a, fe - a, [&](const std::string &raw) {
+						const std::string clean = clean_rdp_name(raw);
+						std::lock_guard<std::mutex> lock(intern_mu);
+						return db->intern(clean);
+					}));
+					rk.push_back((int8_t)-1);
+					trips[r]++; // (one line per read: no two threads touch one counter)
+				} else if (k % 3 == 1) {
+					rk.back() = (int8_t)ranks.get(rest + a, fe - a, [&](const std::string &raw) { return (uint32_t)(uint8_t)rdp_rank_index(raw); });
+				}
+				if (!tb)
 					break;
-				name.push_back(names.get(rest + a, fe - a, [&](const std::string &raw) { return db->intern(clean_rdp_name(raw)); }));
-				rank.push_back((int8_t)-1);
-				trips[r]++;
-			} else if (k % 3 == 1) {
-				rank.back() = (int8_t)ranks.get(rest + a, fe - a, [&](const std::string &raw) { return (uint32_t)(uint8_t)rdp_rank_index(raw); });
+				a = fe + 1;
 			}
-			if (!t)
-				break;
-			a = fe + 1;
 		}
+	});
+	for (unsigned t = 0; t < hw; t++) {
+		name.insert(name.end(), t_name[t].begin(), t_name[t].end());
+		rank.insert(rank.end(), t_rank[t].begin(), t_rank[t].end());
 	}
 	// matched reads come in increasing order, so the triplets already lie in read order
 	code.resize(name.size());

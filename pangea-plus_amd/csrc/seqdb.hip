@@ -1586,6 +1586,52 @@ int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64
 	return pgx::reads_from_fasta_text(std::make_shared<const std::string>(text ? text : "", len), first, count, false, nullptr, out);
 }
 
+// A batch back as FASTA text (">name" + one sequence line per read): the hand-over file between Trim and Classify
+// (README.md:34 -> :96) for batches that were made on the device, and the input of bench.py's file-to-file line.
+int pgx_reads_write_fasta(const pgx_reads *r, const char *path)
+{
+	if (!r || !path)
+		return fail(PGX_E_ARG, "pgx_reads_write_fasta: null argument");
+	return pgx::guard("pgx_reads_write_fasta", [&]() -> int {
+		std::vector<uint64_t> w((size_t)r->n_words + 1, 0), a;
+		PGX_TRY(r->d_fwd.download(w.data(), (size_t)r->n_words));
+		if (r->has_amb) {
+			a.assign((size_t)r->n_words + 1, 0);
+			PGX_TRY(r->d_fwd_amb.download(a.data(), (size_t)r->n_words));
+		}
+		FILE *f = fopen(path, "wb");
+		if (!f)
+			return fail(PGX_E_IO, "cannot open %s for writing", path);
+		std::string out;
+		out.reserve(64u << 20);
+		bool ok = true;
+		for (int64_t i = 0; i < r->n && ok; i++) {
+			out += '>';
+			out += r->name_of(i);
+			out += '\n';
+			const uint32_t L = r->h_len[(size_t)i], w0 = r->h_woff[(size_t)i];
+			const size_t at = out.size();
+			out.resize(at + L + 1);
+			for (uint32_t k = 0; k < L; k++) {
+				const uint64_t word = w[w0 + (k >> 5)];
+				char c = "ACGT"[(word >> (2 * (k & 31))) & 3];
+				if (!a.empty() && ((a[w0 + (k >> 5)] >> (2 * (k & 31))) & 1))
+					c = 'N';
+				out[at + k] = c;
+			}
+			out[at + L] = '\n';
+			if (out.size() > (60u << 20)) {
+				ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+				out.clear();
+			}
+		}
+		ok = ok && fwrite(out.data(), 1, out.size(), f) == out.size();
+		if (fclose(f) != 0 || !ok)
+			return fail(PGX_E_IO, "short write to %s", path);
+		return 0;
+	});
+}
+
 void pgx_reads_close(pgx_reads *r) { delete r; }
 int64_t pgx_reads_count(const pgx_reads *r) { return r ? r->n : 0; }
 
