@@ -94,6 +94,35 @@ def cpu_baseline(cfg, taxdir, sample):
                           sample, res.search_s, res.format_s, res.taxcollect_s, threads, res.consensus_s)}
 
 
+def inclusive(pg, _capi, cfg, db, tmp, first, n):
+    """File to file on a bounded sample: a FASTA file and an RDP file in (page cache), the Consensus text out -- the rate a
+    user of the command lines sees.  The resident rate (`value`) leaves out everything measured here except the kernels."""
+    fa, rf, out = os.path.join(tmp, "incl_reads.fa"), os.path.join(tmp, "incl_rdp.txt"), os.path.join(tmp, "incl_consensus.txt")
+    reads = pg.Reads.from_synth(cfg, first, n)
+    rdp = pg.Rdp.from_synth(cfg, first, n, db)
+    reads.write_fasta(fa)
+    rdp.write_file(rf, reads, db)
+    del reads, rdp
+    t = [time.perf_counter()]
+    r = pg.Reads.from_fasta(fa)
+    t.append(time.perf_counter())
+    p = pg.Rdp.from_file(rf, r, db)
+    t.append(time.perf_counter())
+    hits, recs = _capi.classify_consensus(db, r, p)
+    t.append(time.perf_counter())
+    text = _capi.consensus_format(db, r, hits, recs)
+    with open(out, "wb") as f:
+        f.write(text)
+    t.append(time.perf_counter())
+    size = os.path.getsize(fa) + os.path.getsize(rf)
+    for x in (fa, rf, out):
+        os.remove(x)
+    return {"value": n / (t[-1] - t[0]), "unit": "reads/s",
+            "sample": "%d reads: %.0f MB of FASTA + RDP text in, %.0f MB of consensus text out" % (n, size / 1e6, len(text) / 1e6),
+            "stages_s": {"fasta_to_hbm": t[1] - t[0], "rdp_to_hbm": t[2] - t[1], "classify_consensus": t[3] - t[2],
+                         "consensus_text_to_file": t[4] - t[3]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +131,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inclusive-sample", type=int, default=2_000_000, help="reads of the file-to-file line (0: skip it)")
     ap.add_argument("--n-seq", type=int, default=666667)
     args = ap.parse_args()
 
@@ -294,6 +324,11 @@ def main():
                                    "seed_extend": seed_roof}
             else:
                 out["roofline"] = seed_roof
+            if world == 1 and args.inclusive_sample > 0 and not args.no_cpu_baseline:
+                try:
+                    out["inclusive"] = inclusive(pg, _capi, cfg, db, tmp, 50_000_000, min(args.inclusive_sample, B))
+                except Exception as e:  # the line is still printed
+                    out["inclusive"] = {"error": str(e)}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, tmp, args.cpu_sample)
             else:

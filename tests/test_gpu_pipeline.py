@@ -230,3 +230,32 @@ def test_rdp_lines_of_other_reads_and_repeated_names(pg, chain, tmp_path):
         got.append((hits.format(db, reads), _capi.consensus_format(db, reads, hits, recs), recs.copy()))
     assert got[0][0] == got[1][0] and got[0][1] == got[1][1] and (got[0][2] == got[1][2]).all()
     assert len(got[0][1]) > 20000
+
+
+def test_batch_written_as_files_reads_back_the_same(pg, chain, tmp_path):
+    """pgx_reads_write_fasta / pgx_rdp_write_file: a batch made on the device, written as the FASTA and five-tab RDP text
+    the reference's tools exchange, read back through the file entry points (RDP lines parsed on all host cores), gives
+    the same consensus text."""
+    from pangea_plus_amd import _capi
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
+    reads = pg.Reads.from_synth(cfg, 0, N)
+    rdp = pg.Rdp.from_synth(cfg, 0, N, db)
+    reads.write_fasta(str(tmp_path / "r.fa"))
+    assert (tmp_path / "r.fa").read_bytes() == (chain / "reads.fa").read_bytes()
+    rdp.write_file(str(tmp_path / "rdp.txt"), reads, db)
+    hits, recs = _capi.classify_consensus(db, reads, rdp)
+    want = _capi.consensus_format(db, reads, hits, recs)
+    assert want == (chain / "consensus.txt").read_bytes()
+    r2 = pg.Reads.from_fasta(str(tmp_path / "r.fa"))
+    p2 = pg.Rdp.from_file(str(tmp_path / "rdp.txt"), r2, db)
+    h2, c2 = _capi.classify_consensus(db, r2, p2)
+    assert _capi.consensus_format(db, r2, h2, c2) == want
+    # lines of reads that are not in the batch, a read without a line, repeated names: the cursor rule (Consensus:141-220)
+    lines = (tmp_path / "rdp.txt").read_text().splitlines(True)
+    mixed = ["zz_not_here\t\t\t\t\tBacteria\tdomain\t0.9\n"] + lines[:100] + lines[101:] + [lines[5]]
+    (tmp_path / "rdp_mixed.txt").write_text("".join(mixed))
+    p3 = pg.Rdp.from_file(str(tmp_path / "rdp_mixed.txt"), r2, db)
+    h3, c3 = _capi.classify_consensus(db, r2, p3)
+    assert (c3["hit"][100] == -2) and (np.delete(c3, 100) == np.delete(c2, 100)).all()
