@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inclusive-sample", type=int, default=2_000_000, help="reads of the file-to-file line (0: skip it)")
     ap.add_argument("--n-seq", type=int, default=666667)
+    ap.add_argument("--ungapped", action="store_true", help="blastn -ungapped: stop after the ungapped stage (spec v1, round 1's tables)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -216,6 +217,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_bcast, t_rebuild = float(tt[0].item()), float(tt[1].item())
         db.bind_taxonomy(tax)
+        if args.ungapped:
+            db.set_ungapped(True)
         from pangea_plus_amd.sharding import batch_first_read as sharding_first
         B = args.reads
         batches = []
@@ -297,7 +300,7 @@ def main():
                                        if (B == 10_000_000 and cfg.n_seq == 666667) else "reduced functional run",
                            "reads_per_gpu_per_step": B, "db_bases": int(cfg.n_seq) * int(cfg.seq_len), "db_seqs": int(cfg.n_seq),
                            "read_len": int(cfg.read_len), "parallelism": "read-sharded x%d, index broadcast once over RCCL" % world,
-                           "spec": "pgx-blastn v2 (gapped)"},
+                           "spec": "pgx-blastn v1 (-ungapped)" if args.ungapped else "pgx-blastn v2 (gapped)"},
                 "roofline": None,
                 "stages_ms_last_step": {"seed_extend": last.seed_extend_ms, "gapped": last.gapped_ms, "gapped_wide_hsps": last.gapped_wide,
                                         "group": last.group_ms,

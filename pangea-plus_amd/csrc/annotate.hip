@@ -668,6 +668,16 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open RDP file %s", path);
 	const size_t n = (size_t)reads->n;
+	const bool trace = getenv("PGX_TRACE") != nullptr;
+	auto t_prev = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[pgx trace] rdp_from_file %s: %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+		t_prev = now;
+	};
+	lap("file read");
 	std::vector<uint32_t> off(n + 1, 0), name, trips(n ? n : 1, 0);
 	std::vector<int8_t> rank;
 	std::vector<uint8_t> present(n ? n : 1, 0);
@@ -676,6 +686,7 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	// order; names may repeat).  The reads are indexed by name hash so that a line of a read that is not in this
 	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.
 	const ReadNameIndex index(*reads);
+	lap("name index");
 	static const char kFive[] = "\t\t\t\t\t";
 	const char *base = text.data();
 	// ---- lines
@@ -687,6 +698,7 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		s0 = nl ? (size_t)(nl - base) + 1 : text.size();
 	}
 	const size_t n_lines = ls.size();
+	lap("line starts");
 	ls.push_back(text.size() + (text.empty() || text.back() != '\n' ? 1 : 0)); // (line i ends one byte before the next start)
 	auto line_of = [&](size_t i, const char **line, size_t *len) {
 		*line = base + ls[i];
@@ -719,6 +731,7 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 				line_read[i] = (uint32_t)index.find(line, id_len[i], 0);
 		}
 	});
+	lap("pass 1 (reads of the lines)");
 	{
 		size_t cursor = 0;
 		for (size_t i = 0; i < n_lines; i++) {
@@ -737,16 +750,40 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	// ---- pass 2 (all host cores): the (name, rank, confidence) fields of the lines that belong to a read.  The few
 	// distinct name / rank texts of an RDP file are cleaned and interned once each (per thread; the database's token table
 	// behind a lock)
+	lap("cursor rule");
+	// per-thread memo of the distinct field texts (a few thousand per file): open addressing on the text's hash, the text
+	// itself compared on a hit; a full table (never seen) just stops remembering
 	struct Memo {
-		std::unordered_map<uint64_t, std::vector<std::pair<std::string, uint32_t>>> m;
-		uint32_t get(const char *p, size_t len, const std::function<uint32_t(const std::string &)> &make)
+		struct Slot {
+			uint64_t h = 0;
+			const char *p = nullptr;
+			uint32_t len = 0, value = 0;
+		};
+		std::vector<Slot> slot = std::vector<Slot>(1 << 16);
+		size_t used = 0;
+		// the slot of the text: *hit says whether it already holds a value
+		Slot *find(const char *p, size_t len, bool *hit)
 		{
-			auto &v = m[fnv64_bytes(p, len)];
-			for (auto &e : v)
-				if (e.first.size() == len && memcmp(e.first.data(), p, len) == 0)
-					return e.second;
-			v.emplace_back(std::string(p, len), make(std::string(p, len)));
-			return v.back().second;
+			const uint64_t h = fnv64_bytes(p, len) | 1ull; // 0 marks an empty slot
+			size_t k = (size_t)(h >> 8) & (slot.size() - 1);
+			for (;;) {
+				Slot &e = slot[k];
+				if (e.h == h && e.len == len && memcmp(e.p, p, len) == 0) {
+					*hit = true;
+					return &e;
+				}
+				if (e.h == 0) {
+					*hit = false;
+					if (2 * (used + 1) > slot.size())
+						return nullptr;
+					e.h = h;
+					e.p = p; // (the file's text outlives the memo)
+					e.len = (uint32_t)len;
+					used++;
+					return &e;
+				}
+				k = (k + 1) & (slot.size() - 1);
+			}
 		}
 	};
 	std::mutex intern_mu;
@@ -777,15 +814,26 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 				if (k % 3 == 0) {
 					if (rest_len == 0)
 						break;
-					nm.push_back(names.get(rest + a, fe - a, [&](const std::string &raw) {
-						const std::string clean = clean_rdp_name(raw);
+					bool hit;
+					Memo::Slot *e = names.find(rest + a, fe - a, &hit);
+					uint32_t tok = hit ? e->value : 0u;
+					if (!hit) {
+						const std::string clean = clean_rdp_name(std::string(rest + a, fe - a));
 						std::lock_guard<std::mutex> lock(intern_mu);
-						return db->intern(clean);
-					}));
+						tok = db->intern(clean);
+						if (e)
+							e->value = tok;
+					}
+					nm.push_back(tok);
 					rk.push_back((int8_t)-1);
 					trips[r]++; // (one line per read: no two threads touch one counter)
 				} else if (k % 3 == 1) {
-					rk.back() = (int8_t)ranks.get(rest + a, fe - a, [&](const std::string &raw) { return (uint32_t)(uint8_t)rdp_rank_index(raw); });
+					bool hit;
+					Memo::Slot *e = ranks.find(rest + a, fe - a, &hit);
+					uint32_t rv = hit ? e->value : (uint32_t)(uint8_t)rdp_rank_index(std::string(rest + a, fe - a));
+					if (!hit && e)
+						e->value = rv;
+					rk.back() = (int8_t)rv;
 				}
 				if (!tb)
 					break;
@@ -793,10 +841,12 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			}
 		}
 	});
+	lap("pass 2 (fields)");
 	for (unsigned t = 0; t < hw; t++) {
 		name.insert(name.end(), t_name[t].begin(), t_name[t].end());
 		rank.insert(rank.end(), t_rank[t].begin(), t_rank[t].end());
 	}
+	lap("concatenate");
 	// matched reads come in increasing order, so the triplets already lie in read order
 	code.resize(name.size());
 	for (size_t k = 0; k < name.size(); k++)
