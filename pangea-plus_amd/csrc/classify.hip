@@ -358,6 +358,7 @@ struct WaveLds {
 
 struct OutView {
 	pgx_hit *main, *ovf;
+	uint8_t *main_key, *ovf_key; // gapped mode: per slot the work estimate of the gapped stage (mismatches left | right << 4)
 	unsigned long long main_cap, ovf_cap;
 	// [0] main-table slots reserved (chunks), [1] probes, [2] postings, [3] seed runs, [4] overflow hits,
 	// [5] hits stored in the main table, [6] candidates that survive the duplicate filter
@@ -389,28 +390,59 @@ __device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
 	return h;
 }
 
+// Spec v2: what the seed stage hands to the gapped stage is not a hit but a SEED RECORD in the same 32 bytes, holding
+// what a round of the gapped kernel needs without a second look-up: read, subject, qstart = word offset of the read,
+// qend = anchor (read position on the hit's strand), sstart = database position of the anchor, send = strand,
+// score = read length, mismatch / gapopen = mismatches of the diagonal left / right of the anchor (capped at 15).
+// Staged 16-byte form (two short reads per wavefront): subject, database position, anchor | strand << 31, estimates.
+__device__ __forceinline__ uint4 pack_seed(const pgx_hit &h)
+{
+	return make_uint4((uint32_t)h.subject, (uint32_t)h.sstart, (uint32_t)h.qend | ((uint32_t)h.send << 31),
+			  (uint32_t)h.mismatch | ((uint32_t)h.gapopen << 4));
+}
+
+__device__ __forceinline__ pgx_hit unpack_seed(const uint4 c, uint32_t read, uint32_t woff, int L)
+{
+	pgx_hit h;
+	h.read = (int32_t)read;
+	h.subject = (int32_t)c.x;
+	h.qstart = (int32_t)woff;
+	h.qend = (int32_t)(c.z & 0x7FFFFFFFu);
+	h.sstart = (int32_t)c.y;
+	h.send = (int32_t)(c.z >> 31);
+	h.score = L;
+	h.mismatch = (uint16_t)(c.w & 15u);
+	h.gapopen = (uint16_t)((c.w >> 4) & 15u);
+	return h;
+}
+
+__device__ __forceinline__ uint8_t seed_key(const pgx_hit &h) { return (uint8_t)((h.mismatch & 15u) | ((h.gapopen & 15u) << 4)); }
+
 // PACKED: two reads share the wavefront, read slot `rs` stages 16-byte records
 template <bool PACKED>
-__device__ __forceinline__ void emit_hit(WaveLds *st, int rs, const OutView &ov, const pgx_hit &h)
+__device__ __forceinline__ void emit_hit(WaveLds *st, int rs, const OutView &ov, const pgx_hit &h, bool gapped)
 {
 	unsigned int slot = atomicAdd(&st->n[rs], 1u);
 	if (slot < (unsigned)kStage) {
 		if (PACKED)
-			st->chit[rs * kStage + slot] = pack_hit(h);
+			st->chit[rs * kStage + slot] = gapped ? pack_seed(h) : pack_hit(h);
 		else
 			st->hit[slot] = h;
 	} else {
 		atomicAdd(&st->direct[rs], 1u);
 		unsigned long long g = atomicAdd(&ov.counters[4], 1ull);
-		if (g < ov.ovf_cap)
+		if (g < ov.ovf_cap) {
 			ov.ovf[g] = h;
+			if (gapped)
+				ov.ovf_key[g] = seed_key(h);
+		}
 	}
 }
 
 // One candidate = one (strand, probe position, posting).  `tested` says the index already proved that
 // this probe is the left-most one of its exact run (test 1 below).
 template <bool AMB, class Mask, class Emit>
-__device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read,
+__device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read, uint32_t woff,
 						   int strand, int qp, uint32_t p, bool tested, bool claimed, uint32_t s,
 						   uint32_t s_start, uint32_t s_end, Emit &emit, unsigned long long &n_runs)
 {
@@ -543,26 +575,9 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 			pgx_hit h;
 			h.read = (int32_t)read;
 			h.subject = (int32_t)s;
-			// spec v2: this is an INITIAL HSP; the gapped stage (gapped.hip) extends it from its ANCHOR: the first base of
-			// the run of matches that holds the last matching position at or before the HSP's middle column (S3b; an
-			// extension from the middle costs the least: its work grows with the square of the differences on a side).
-			// The anchor's offset from the HSP's start travels in the score field.
 			h.score = len + best + bestr;
 			h.mismatch = (uint16_t)(mm_best + mmr_best);
 			h.gapopen = 0;
-			if (db.gapped) {
-				int q = bl + (br - bl) / 2;
-				while (M.first_ge(q) == q)
-					q--; // (bl is a match)
-				int anchor = M.last_lt(q) + 1;
-				anchor = anchor > bl ? anchor : bl;
-				h.score = anchor - bl;
-				// work estimate for the gapped stage (it groups sides of similar cost): mismatches of the diagonal left of
-				// the anchor and right of it, capped at 15
-				const int ml = M.count_range(D.lo, anchor), mr = M.count_range(anchor, D.hi);
-				h.mismatch = (uint16_t)(ml < 15 ? ml : 15);
-				h.gapopen = (uint16_t)(mr < 15 ? mr : 15);
-			}
 			const int64_t sl = D.dstart + bl - (int64_t)s_start + 1, sr = D.dstart + br - (int64_t)s_start + 1;
 			if (!strand) {
 				h.qstart = bl + 1;
@@ -574,6 +589,25 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				h.qend = L - bl;
 				h.sstart = (int32_t)sr;
 				h.send = (int32_t)sl;
+			}
+			if (db.gapped) {
+				// spec v2: this is an INITIAL HSP; the gapped stage (gapped.hip) extends it from its ANCHOR: the first base of
+				// the run of matches that holds the last matching position at or before the HSP's middle column (S3b; an
+				// extension from the middle costs the least: its work grows with the square of the differences on a side).
+				// What leaves here is a seed record (see pack_seed), not a hit.
+				int q = bl + (br - bl) / 2;
+				while (M.first_ge(q) == q)
+					q--; // (bl is a match)
+				int anchor = M.last_lt(q) + 1;
+				anchor = anchor > bl ? anchor : bl;
+				const int ml = M.count_range(D.lo, anchor), mr = M.count_range(anchor, D.hi);
+				h.qstart = (int32_t)woff;
+				h.qend = anchor;
+				h.sstart = (int32_t)(uint32_t)(D.dstart + anchor);
+				h.send = strand;
+				h.score = L;
+				h.mismatch = (uint16_t)(ml < 15 ? ml : 15);
+				h.gapopen = (uint16_t)(mr < 15 ? mr : 15);
 			}
 			if (PGX_DBG_STOP(db) != 7)
 				emit(h);
@@ -668,8 +702,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				base = atomicAdd(&ov.counters[4], (unsigned long long)n);
 			base = __shfl(base, 0);
 			for (unsigned int i = lane; i < n; i += 64)
-				if (base + i < ov.ovf_cap)
-					ov.ovf[base + i] = RPW == 2 ? unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA) : st->hit[i];
+				if (base + i < ov.ovf_cap) {
+					const pgx_hit hh = RPW == 2 ? (db.gapped ? unpack_seed(st->chit[rs * SLOT_CAP + i], rs ? rB : rA, rs ? wB : wA, rs ? LB : LA)
+										  : unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA))
+								     : st->hit[i];
+					ov.ovf[base + i] = hh;
+					if (db.gapped)
+						ov.ovf_key[base + i] = seed_key(hh);
+				}
 			if (rs)
 				emitted[1] += n, frag[1] = true;
 			else
@@ -696,11 +736,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 					const uint64_t *a = strand ? rd.rc_amb : rd.fwd_amb;
 					ra = a ? a + cw0 : nullptr;
 				}
-				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh); };
+				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh, db.gapped != 0); };
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB, (NW > 0 ? NW : 3)>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, DenseMask<AMB, (NW > 0 ? NW : 3)>>(db, rw, ra, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 				else
-					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 			}
 			lds_fence();
 			// a read's stage more than half full in the middle of the work: the read becomes fragmented
@@ -963,10 +1003,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 					n_main += lane == 0 ? n : 0;
 				}
 				pgx_hit *dst = fr ? ov.ovf : ov.main;
+				uint8_t *dkey = fr ? ov.ovf_key : ov.main_key;
 				const unsigned long long dcap = fr ? ov.ovf_cap : ov.main_cap;
 				for (unsigned int i = lane; i < n; i += 64)
-					if (base + i < dcap)
-						dst[base + i] = RPW == 2 ? unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA) : st->hit[i];
+					if (base + i < dcap) {
+						const pgx_hit hh = RPW == 2 ? (db.gapped ? unpack_seed(st->chit[rs * SLOT_CAP + i], rs ? rB : rA, rs ? wB : wA, rs ? LB : LA)
+											  : unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA))
+									     : st->hit[i];
+						dst[base + i] = hh;
+						if (db.gapped)
+							dkey[base + i] = seed_key(hh);
+					}
 				em += n;
 				if (!fr)
 					start = (uint32_t)base;
@@ -1717,6 +1764,7 @@ struct Workspace {
 	DevBuf<unsigned long long> counters; // [0..7] seed stage (OutView), [8] reads passed to the big-read path, [9] 33..64-hit list
 	unsigned long long *h_counters = nullptr; // pinned mirror of counters + the gapped stage's list count
 	DevBuf<pgx_hit> scratch, ovf;
+	DevBuf<uint8_t> scratch_key, ovf_key; // gapped mode: the gapped stage's work estimate per slot of the two tables
 	DevBuf<uint32_t> partial, cursor, big_list, read_start, mid_list;
 	DevBuf<uint32_t> piece_cnt, piece_off, parent_start; // batches searched piece by piece
 	DevBuf<pgx_consensus_rec> recs;
@@ -1820,11 +1868,17 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		PGX_TRY(out->d_hits.ensure(table_cap));
 		cap = scratch.n;
 		ovf_cap = ovf.n;
+		if (dv.gapped) {
+			PGX_TRY(ws.scratch_key.ensure(cap));
+			PGX_TRY(ws.ovf_key.ensure(ovf_cap));
+		}
 		table_cap = out->d_hits.n;
 		PGX_HIP(hipMemsetAsync(ws.counters.data(), 0, kNCounters * sizeof(unsigned long long), st));
 		OutView ov;
 		ov.main = scratch.data();
 		ov.ovf = ovf.data();
+		ov.main_key = ws.scratch_key.data();
+		ov.ovf_key = ws.ovf_key.data();
 		ov.main_cap = cap;
 		ov.ovf_cap = ovf_cap;
 		ov.counters = ws.counters.data();
@@ -1873,8 +1927,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		if (dv.gapped) {
 			ReadsView all = rv;
 			all.n = (uint32_t)ns;
-			PGX_TRY(gapped_stage(dv, all, scratch.data(), rs_ptr, rc_ptr, ovf.data(), ws.counters.data() + 4, ovf_cap, long_reads, cap,
-					     (int)sr->max_len, ws.gapped, st));
+			PGX_TRY(gapped_stage(dv, all, scratch.data(), ws.scratch_key.data(), rs_ptr, rc_ptr, ovf.data(), ws.ovf_key.data(),
+					     ws.counters.data() + 4, ovf_cap, long_reads, cap, (int)sr->max_len, ws.gapped, st));
 			trace_point("gapped_stage");
 		}
 		ws.ev.mark(2, st);

@@ -278,8 +278,8 @@ struct GappedWork {
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats)
 	DevBuf<uint2> side_main, side_ovf; // per table slot: the left side's extension, parked until the right side is done
 };
-int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint32_t *read_start, const uint32_t *read_cnt,
-		 pgx_hit *ovf_table, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
+int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
+		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
 		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream);
 
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)

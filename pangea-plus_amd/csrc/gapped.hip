@@ -119,30 +119,29 @@ struct GapView {
 	const uint32_t *len, *woff;
 	const uint64_t *dbw, *dba;
 	const uint32_t *seq_off;
+	const uint8_t *key; // per slot of the table this launch works on: the seed stage's work estimate
 	const uint32_t *amb_blk; // one bit per 512-base block of the database that holds an ambiguity letter (or null)
 };
 
-// the initial HSP (seed stage, gapped mode): score = offset of the first base of the seed run from the HSP's start, on
-// the strand of the hit
+// the seed record of the seed stage (classify.hip: pack_seed): everything a round needs except the subject's ends
 struct Anchor {
 	int strand, L, qa, sa, slen;
 	int64_t S0;
+	uint32_t gpos; // database position of the anchor
 	GapSeqs s;
 };
 
 __device__ __forceinline__ Anchor anchor_of(const GapView &v, const pgx_hit &h)
 {
 	Anchor a;
-	const uint32_t r = (uint32_t)h.read;
-	a.L = (int)v.len[r];
-	a.strand = h.sstart > h.send;
-	const int bl = a.strand ? a.L - h.qend : h.qstart - 1;
-	const int sl = (a.strand ? h.send : h.sstart) - 1;
-	a.qa = bl + h.score;
-	a.sa = sl + h.score;
+	a.strand = h.send;
+	a.L = h.score;
+	a.qa = h.qend;
+	a.gpos = (uint32_t)h.sstart;
 	a.S0 = (int64_t)v.seq_off[h.subject];
 	a.slen = (int)(v.seq_off[h.subject + 1] - v.seq_off[h.subject]);
-	const uint32_t w0 = v.woff[r];
+	a.sa = (int)((int64_t)a.gpos - a.S0);
+	const uint32_t w0 = (uint32_t)h.qstart;
 	a.s.rw = (a.strand ? v.rc : v.fwd) + w0;
 	const uint64_t *ra = a.strand ? v.rc_amb : v.fwd_amb;
 	a.s.ra = ra ? ra + w0 : nullptr;
@@ -385,10 +384,8 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 				for (uint32_t it = 0; it < n_it; it += 64) {
 					const uint32_t item = it + lane;
 					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
-					if (item < n_it) {
-						const uint32_t mg = reinterpret_cast<const uint32_t *>(p)[7];
-						atomicAdd(&lds.bucket[(side ? mg >> 16 : mg) & 15u], 1u);
-					}
+					if (item < n_it)
+						atomicAdd(&lds.bucket[(v.key[p - table] >> (4 * side)) & 15u], 1u);
 				}
 				lds_sync();
 				{
@@ -408,8 +405,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 					const uint32_t item = it + lane;
 					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
 					if (item < n_it) {
-						const uint32_t mg = reinterpret_cast<const uint32_t *>(p)[7];
-						const uint32_t slot = atomicAdd(&lds.bucket[(side ? mg >> 16 : mg) & 15u], 1u);
+						const uint32_t slot = atomicAdd(&lds.bucket[(v.key[p - table] >> (4 * side)) & 15u], 1u);
 						lds.order[slot] = (uint16_t)item;
 					}
 				}
@@ -426,16 +422,17 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 					Anchor a;
 					a.strand = a.L = a.qa = a.sa = a.slen = 0;
 					a.S0 = 0;
+					a.gpos = 0;
 					a.s.rw = a.s.ra = a.s.dbw = a.s.dba = nullptr;
 					bool on = false;
-					int win0 = 0;
+					int awin = 0; // the anchor's position in the staged window
 					uint2 parked = make_uint2(0u, 0u);
 					if (mine) {
 						h = *hp;
 						a = anchor_of(v, h);
 						// the database window of this HSP: from kGFastD + 16 bases left of where the read's first base
 						// would lie, in whole 16-base words
-						const int64_t lo = (a.S0 + a.sa - a.qa - kGFastD - 16) >> 4; // word index (may be negative: front padding)
+						const int64_t lo = ((int64_t)a.gpos - a.qa - kGFastD - 16) >> 4; // word index (may be negative: front padding)
 						bool wide = a.L > MAXL;
 						if (side == 1) {
 							parked = side_res[slot];
@@ -464,11 +461,11 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 							for (int w = r0; w < r1 && w < Lds::kRd; w++)
 								rdw[w] = gr[w];
 							const uint32_t *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
-							const int mid = (int)(((a.S0 + a.sa) >> 4) - lo); // window word that holds the anchor
+							const int mid = (int)(((int64_t)a.gpos >> 4) - lo); // window word that holds the anchor
 							const int d0w = side ? mid : 0, d1w = side ? Lds::kDb : mid + 2;
 							for (int w = d0w; w < d1w && w < Lds::kDb; w++)
 								dbwin[w] = gd[w];
-							win0 = (int)(lo * 16 - a.S0);
+							awin = (int)((int64_t)a.gpos - lo * 16);
 							on = true;
 						}
 					}
@@ -482,9 +479,9 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 						continue; // (probe: ordering + staging only)
 					}
 					if (side == 0)
-						ok = greedy_rows(rdw, dbwin, on, -1, a.qa - 1, a.sa - 1 - win0, a.qa, a.sa, sd);
+						ok = greedy_rows(rdw, dbwin, on, -1, a.qa - 1, awin - 1, a.qa, a.sa, sd);
 					else
-						ok = greedy_rows(rdw, dbwin, on, +1, a.qa, a.sa - win0, a.L - a.qa, a.slen - a.sa, sd);
+						ok = greedy_rows(rdw, dbwin, on, +1, a.qa, awin, a.L - a.qa, a.slen - a.sa, sd);
 					if (mine) {
 						if (side == 0) {
 							// parked: i | j << 10 | mismatches << 20 | gap openings << 25 ; gap columns | wide << 31
@@ -647,8 +644,8 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 	}
 }
 
-int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint32_t *read_start, const uint32_t *read_cnt,
-		 pgx_hit *ovf_table, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
+int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
+		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
 		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream)
 {
 	GapView v;
@@ -677,9 +674,11 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy)
 #define PGX_GAPPED_LAUNCH(ML)                                                                                                                \
 	do {                                                                                                                                 \
+		v.key = main_key;                                                                                                            \
 		hipLaunchKernelGGL((k_gapped_fast<false, ML>), dim3(grid ? grid : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
 				   gw.side_main.data(), dbg);                                                                                        \
+		v.key = ovf_key;                                                                                                             \
 		hipLaunchKernelGGL((k_gapped_fast<true, ML>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
 				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
 				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg);                                                              \
