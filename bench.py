@@ -83,15 +83,24 @@ def cpu_baseline(cfg, taxdir, sample):
     oc = OCfg(cfg.seed, cfg.n_seq, cfg.seq_len, cfg.n_genus, cfg.read_seed, cfg.read_len)
     threads = max(1, min(os.cpu_count() or 1, 16))
     lib.o_bench_chain.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char_p, C.c_void_p]
-    res = Res()
-    rc = lib.o_bench_chain(C.byref(oc), 0, sample, threads, taxdir.encode(), C.byref(res))
-    if rc != 0:
-        return None
-    t = res.search_s + res.format_s + res.taxcollect_s + res.consensus_s
-    return {"value": sample / t, "unit": "reads/s", "cores": threads, "kind": "port",
-            "sample": "%d reads of the same stream vs the full database: search %.1fs + format %.1fs + taxcollector %.1fs "
-                      "(%d threads each) + consensus %.1fs (one thread: a cursor walk)" % (
-                          sample, res.search_s, res.format_s, res.taxcollect_s, threads, res.consensus_s)}
+    # two runs on half the sample each, the faster one reported (the figure swung 11.5-15.9 k between runs of round 1)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    best, runs = None, []
+    half = max(1, sample // 2)
+    for k in range(2):
+        res = Res()
+        rc = lib.o_bench_chain(C.byref(oc), k * half, half, threads, taxdir.encode(), C.byref(res))
+        if rc != 0:
+            return None
+        t = res.search_s + res.format_s + res.taxcollect_s + res.consensus_s
+        runs.append(half / t)
+        if best is None or t < best[0]:
+            best = (t, res.search_s, res.format_s, res.taxcollect_s, res.consensus_s)
+    t, se, fo, tc, co = best
+    return {"value": half / t, "unit": "reads/s", "cores": threads, "kind": "port", "runs": runs,
+            "sample": "best of 2 runs of %d reads of the same stream vs the full database (spec v2: gapped): search %.1fs + format "
+                      "%.1fs + taxcollector %.1fs (%d threads each) + consensus %.1fs (one thread: a cursor walk)" % (
+                          half, se, fo, tc, threads, co)}
 
 
 def inclusive(pg, _capi, cfg, db, tmp, first, n):
