@@ -38,7 +38,23 @@ static inline int is_match(const uint8_t *q, const uint8_t *s, int64_t d, int32_
 	return q[k] < 4 && q[k] == s[k + d];
 }
 
-void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
+/* S3d: an exact run [a, b) of the query strand is a seed only if one of its 28-base windows touches no masked base */
+int o_blast_run_is_seed(const uint8_t *qmask, int32_t a, int32_t b)
+{
+	if (b - a < O_BLAST_W)
+		return 0;
+	if (!qmask)
+		return 1;
+	int32_t clean = 0;
+	for (int32_t k = a; k < b; k++) {
+		clean = qmask[k] ? 0 : clean + 1;
+		if (clean >= O_BLAST_W)
+			return 1;
+	}
+	return 0;
+}
+
+void o_blast_diag_hsps(const uint8_t *q, const uint8_t *qmask, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
 		       void (*emit)(void *, int32_t, int32_t, int32_t, int32_t, int32_t), void *ctx)
 {
 	int32_t lo = d < 0 ? (int32_t)(-d) : 0;
@@ -55,7 +71,7 @@ void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t
 		int32_t j = i;
 		while (j < hi && is_match(q, s, d, j))
 			j++;
-		if (j - i >= O_BLAST_W && i >= covered) {
+		if (o_blast_run_is_seed(qmask, i, j) && i >= covered) {
 			int32_t best = 0, cur = 0, bl = i;
 			for (int32_t k = i - 1; k >= lo; k--) {
 				cur += is_match(q, s, d, k) ? O_BLAST_REWARD : O_BLAST_PENALTY;
@@ -96,7 +112,7 @@ void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t
 }
 
 /* ---------------- statistics (S4) ---------------- */
-int o_blast_gapped = 1, o_blast_prune = 1;
+int o_blast_gapped = 1, o_blast_prune = 1, o_blast_dust = 1;
 
 void o_blast_stats_init(o_blast_stats *st, int64_t db_len, int64_t db_nseq, int gapped)
 {
@@ -337,6 +353,18 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 			rcb[o + k] = b < 4 ? (uint8_t)(3 - b) : O_AMB;
 		}
 	}
+	/* S3d: low-complexity mask of every query, forward and (the same mask reversed) reverse-complement strand */
+	uint8_t *maskf = NULL, *maskr = NULL;
+	if (o_blast_dust) {
+		maskf = (uint8_t *)calloc((size_t)queries->total + 1, 1);
+		maskr = (uint8_t *)calloc((size_t)queries->total + 1, 1);
+		for (int64_t qi = 0; qi < nq; qi++) {
+			int64_t o = queries->off[qi], L = queries->off[qi + 1] - o;
+			o_dust_mask(queries->base + o, (int32_t)L, maskf + o);
+			for (int64_t k = 0; k < L; k++)
+				maskr[o + k] = maskf[o + L - 1 - k];
+		}
+	}
 	/* lookup table over all query 12-mers of both strands */
 	lut_t lut;
 	lut.head = (int32_t *)malloc(sizeof(int32_t) << (2 * LUT_K));
@@ -421,6 +449,7 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 				int64_t o = queries->off[qi];
 				int32_t qlen = (int32_t)(queries->off[qi + 1] - o);
 				const uint8_t *q = st ? rcb + o : queries->base + o;
+				const uint8_t *qm = maskf ? (st ? maskr + o : maskf + o) : NULL;
 				int64_t d = (int64_t)spos - qp;
 				int32_t lo = d < 0 ? (int32_t)(-d) : 0;
 				int32_t hi = (int64_t)qlen < (int64_t)slen - d ? qlen : (int32_t)((int64_t)slen - d);
@@ -429,7 +458,7 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 					a--;
 				while (b < hi && is_match(q, s, d, b))
 					b++;
-				if (b - a < O_BLAST_W)
+				if (!o_blast_run_is_seed(qm, a, b))
 					continue;
 				if (qp - LUT_STRIDE >= a)
 					continue; /* an earlier scanned word of the same run reports it */
@@ -441,13 +470,13 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 					int32_t e2 = k;
 					while (k - 1 >= lo && is_match(q, s, d, k - 1))
 						k--;
-					if (e2 - k + 1 >= O_BLAST_W)
+					if (o_blast_run_is_seed(qm, k, e2 + 1))
 						first = 0;
 				}
 				if (!first)
 					continue;
 				emit_ctx c = { &tv[tid], qi, (int32_t)subj, st, qlen, slen, d, q, s };
-				o_blast_diag_hsps(q, qlen, s, slen, d, emit_hit, &c);
+				o_blast_diag_hsps(q, qm, qlen, s, slen, d, emit_hit, &c);
 			}
 		}
 	}
@@ -541,6 +570,8 @@ int o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, i
 	free(lut.qs);
 	free(lut.qpos);
 	free(rcb);
+	free(maskf);
+	free(maskr);
 	return 0;
 }
 

@@ -26,6 +26,8 @@ static int run_blastn(int argc, char **argv)
 			o_blast_gapped = 0;
 		if (strcmp(argv[i], "-no_prune") == 0) /* the greedy extension without its result-neutral bound cut */
 			o_blast_prune = 0;
+		if (strcmp(argv[i], "-dust") == 0 && i + 1 < argc && strcmp(argv[i + 1], "no") == 0) /* blastn -dust no */
+			o_blast_dust = 0;
 	}
 	if (!q || !d || !o || strcmp(f, "6") != 0) {
 		fprintf(stderr, "usage: blastn -query F -db DB.fa -outfmt 6 -out O\n");

@@ -98,9 +98,13 @@ void o_greedy_extend(const uint8_t *a, int32_t M, const uint8_t *b, int32_t N, i
 /* switches of the restatement (defaults 1, 1): gapped = 0 gives `blastn -ungapped` (spec v1); prune = 0 runs the greedy
  * extension without the result-neutral bound cut */
 extern int o_blast_gapped, o_blast_prune;
+/* S3d (o_dust.c): mask[i] = 1 for the bases of every perfect low-complexity interval; o_blast_dust = 0 is `-dust no` */
+void o_dust_mask(const uint8_t *base, int32_t len, uint8_t *mask);
+extern int o_blast_dust;
 
 /* all HSPs of one diagonal (spec 4.x): q/s are base arrays, d = s_pos - q_pos */
-void o_blast_diag_hsps(const uint8_t *q, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
+int  o_blast_run_is_seed(const uint8_t *qmask, int32_t a, int32_t b);
+void o_blast_diag_hsps(const uint8_t *q, const uint8_t *qmask, int32_t qlen, const uint8_t *s, int32_t slen, int64_t d,
 		       void (*emit)(void *ctx, int32_t qlo, int32_t qhi, int32_t score, int32_t mism, int32_t seed), void *ctx);
 /* search every query (both strands) against db; hits come back in the spec's output order */
 int  o_blast_search(const o_seqset *queries, const o_seqset *db, o_hitvec *out, int threads);

@@ -58,7 +58,48 @@ def read_fa(p):
     return out
 
 
-def diag_hsps(q, s, d, W=28, X=10):
+def dust_mask(seq, W=64, level=20):
+    """S3d: the definition of symmetric DUST (Morgulis et al. 2006): triplet intervals of at most W - 2 triplets whose score
+    (sum of c(c-1)/2 over triplet values, divided by triplets - 1) exceeds level / 10 and is not beaten by a sub-interval."""
+    from fractions import Fraction
+    n, nt = len(seq), len(seq) - 2
+    mask = [False] * n
+    if nt < 2:
+        return mask
+    trip = [seq[i:i + 3] if all(c in "ACGT" for c in seq[i:i + 3]) else None for i in range(nt)]
+    best = {}   # (a, b) -> highest score of any sub-interval of [a, b] with at least two triplets, or None
+    for a in range(nt - 1, -1, -1):
+        cnt, r = {}, 0
+        for b in range(a, min(nt, a + W - 2)):
+            if trip[b] is None:
+                break
+            r += cnt.get(trip[b], 0)
+            cnt[trip[b]] = cnt.get(trip[b], 0) + 1
+            s = Fraction(r, b - a) if b > a else None
+            subs = [x for x in (best.get((a + 1, b)), best.get((a, b - 1))) if x is not None]
+            sub = max(subs) if subs else None
+            if s is not None and s * 10 > level and (sub is None or sub <= s):
+                for k in range(a, b + 3):
+                    mask[k] = True
+            cands = [x for x in (s, sub) if x is not None]
+            best[(a, b)] = max(cands) if cands else None
+    return mask
+
+
+def run_is_seed(qmask, a, b, W=28):
+    if b - a < W:
+        return False
+    if qmask is None:
+        return True
+    clean = 0
+    for k in range(a, b):
+        clean = 0 if qmask[k] else clean + 1
+        if clean >= W:
+            return True
+    return False
+
+
+def diag_hsps(q, s, d, W=28, X=10, qmask=None):
     lo, hi = max(0, -d), min(len(q), len(s) - d)
     res = []
     if hi - lo < W:
@@ -73,7 +114,7 @@ def diag_hsps(q, s, d, W=28, X=10):
         j = i
         while j < hi and mm(j):
             j += 1
-        if j - i >= W and i >= covered:
+        if run_is_seed(qmask, i, j, W) and i >= covered:
             best = cur = 0
             bl = i
             for k in range(i - 1, lo - 1, -1):
@@ -293,18 +334,21 @@ def test_greedy_extension_is_optimal_and_bound_cut_is_neutral(oracle_bin):
     assert n_gapped > 60
 
 
-def brute_force_v2(queries, db):
-    """Spec v2: the initial HSPs of v1, each extended with gaps from the first base of its seed run (S3b), then the
-    hits of one (query, subject) that describe one alignment reduced to the first in the S5 order (S3c)."""
+def brute_force_v2(queries, db, dust=True):
+    """Spec v2: the initial HSPs of v1 (seeds: exact runs with a 28-base window free of DUST-masked query bases, S3d), each
+    extended with gaps from its anchor (S3b), then the hits of one (query, subject) that describe one alignment reduced to
+    the first in the S5 order (S3c)."""
     rows = []
     for qn, q in queries:
         Lq = len(q)
         rcq = "".join(COMP.get(c, "N") for c in reversed(q))
+        mf = dust_mask(q) if dust else None
+        masks = (mf, mf[::-1] if mf is not None else None)
         for sn, s in db:
             group = []
             for strand, qq in ((0, q), (1, rcq)):
                 for d in range(-(Lq - 28), len(s) - 28 + 1):
-                    for _bl, _br, _score, _mism, seed in diag_hsps(qq, s, d):
+                    for _bl, _br, _score, _mism, seed in diag_hsps(qq, s, d, qmask=masks[strand]):
                         qa, sa = seed, seed + d
                         li, lj, ls2, lm, lo, lg = greedy(qq[:qa][::-1], s[:sa][::-1])
                         ri, rj, rs2, rm, ro, rg = greedy(qq[qa:], s[sa:])
@@ -373,6 +417,78 @@ def test_blast_mode_v2_equals_brute_force_of_the_spec(oracle_bin, tmp_path):
     assert outs[0] == outs[1] == outs[2]   # neither threads nor the bound cut change a byte
     assert sum(1 for l in outs[0] if l.split("\t")[5] != "0") > 20   # gapopen > 0 rows exist
     assert len(want) > 40
+
+
+def test_dust_mask_and_masked_seeds(oracle_bin, tmp_path):
+    """S3d: the oracle's DUST mask equals the Python restatement of the definition on random and low-complexity sequences
+    (homopolymers, di- and tri-nucleotide repeats, N's), and the tables with and without `-dust no` equal the brute force."""
+    import ctypes
+    import random
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(oracle_bin), "..", "liboracle.so"))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    rng = random.Random(4)
+
+    def lowc(n):
+        kind = rng.randrange(5)
+        if kind == 0:
+            return rng.choice("ACGT") * n
+        if kind == 1:
+            u = rng.choice(["AC", "GT", "AT", "CG", "AG"])
+            return (u * n)[:n]
+        if kind == 2:
+            u = "".join(rng.choice("ACGT") for _ in range(3))
+            return (u * n)[:n]
+        if kind == 3:
+            return "".join(rng.choice("AAAAAAC") for _ in range(n))
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    n_masked = 0
+    seqs = []
+    for case in range(120):
+        L = rng.choice([5, 30, 64, 150, 150, 300])
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            n = rng.choice([6, 7, 8, 12, 20, 40, 70])
+            if n < L:
+                p_ = rng.randrange(0, L - n)
+                s = s[:p_] + lowc(n) + s[p_ + n:]
+        if case % 7 == 0 and L > 10:
+            s = s[:L // 3] + "N" + s[L // 3 + 1:]
+        want = dust_mask(s)
+        buf = (ctypes.c_uint8 * max(1, len(s)))()
+        lib.o_dust_mask(bytes(code.get(c, 4) for c in s), len(s), buf)
+        assert [bool(x) for x in buf[:len(s)]] == want, (case, s)
+        n_masked += any(want)
+        seqs.append(s)
+    assert n_masked > 25
+    assert not any(dust_mask("".join(rng.choice("ACGT") for _ in range(150)))[:0])
+    assert all(dust_mask("A" * 7)) and not any(dust_mask("A" * 6))   # seven of one letter: five triplets, 10 / 4 > 2
+    # tables: a small database that holds the low-complexity stretches too, reads cut from it
+    dbs = [s for s in seqs if len(s) >= 150][:14]
+    db, rd, out = tmp_path / "db.fa", tmp_path / "reads.fa", tmp_path / "hits.tsv"
+    db.write_text("".join(">gi|%d|x|d%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(dbs)))
+    reads = []
+    for i in range(30):
+        s = rng.choice(dbs)
+        o = rng.randrange(0, len(s) - 100 + 1)
+        w = list(s[o:o + rng.choice([100, 150])])
+        for p_ in rng.sample(range(len(w)), rng.choice([0, 1, 2])):
+            w[p_] = rng.choice("ACGT")
+        w = "".join(w)
+        if i % 2:
+            w = "".join(COMP.get(c, "N") for c in reversed(w))
+        reads.append(">m%d\n%s\n" % (i, w))
+    rd.write_text("".join(reads))
+    got = {}
+    for flags, dust in ((["-dust", "no"], False), ([], True)):
+        assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(out)] + flags)[0] == 0
+        rows = set()
+        for l in out.read_text().splitlines():
+            f = l.split("\t")
+            rows.add((f[0], f[1], f[2], int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[9])))
+        want, _n = brute_force_v2(read_fa(str(rd)), read_fa(str(db)), dust=dust)
+        assert rows == want, dust
+        got[dust] = rows
+    assert got[True] != got[False] and len(got[True]) > 10   # the mask removes seeds, not everything
 
 
 def test_blast_statistics_and_formatting(oracle_bin, tmp_path):
