@@ -94,10 +94,12 @@ typedef struct {
 	int outfmt;             /* -outfmt, only 6 */
 	int rank, world_size;   /* read sharding: this process handles block `rank` of `world_size` */
 	int ungapped;           /* -ungapped */
+	int no_dust;            /* -dust no (default: -dust "20 64 1", BLAST+'s default: low-complexity stretches of the query seed nothing) */
 } pgx_blastn_opts;
 int pgx_blastn_run(const pgx_blastn_opts *opts);
 /* the same switch for searches through a database handle (pgx_blast_search, pgx_classify_consensus): per handle */
 int pgx_db_set_ungapped(pgx_db *db, int ungapped);
+int pgx_db_set_dust(pgx_db *db, int dust); /* 1 (default): DUST-masked bases of the reads seed nothing; 0: `-dust no` */
 
 /* ------------------------------------------------------------------------------------------
  * Classify, SOAP verb  —  `soap -a reads -D ref.index -o out -p 8 -M 4` (README.md:134;

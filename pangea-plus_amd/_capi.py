@@ -69,7 +69,7 @@ class _DbShape(C.Structure):
 
 class _BlastnOpts(C.Structure):
     _fields_ = [("query_path", C.c_char_p), ("db_prefix", C.c_char_p), ("out_path", C.c_char_p), ("outfmt", C.c_int),
-                ("rank", C.c_int), ("world_size", C.c_int), ("ungapped", C.c_int)]
+                ("rank", C.c_int), ("world_size", C.c_int), ("ungapped", C.c_int), ("no_dust", C.c_int)]
 
 
 class _SoapOpts(C.Structure):
@@ -86,7 +86,7 @@ REC_DTYPE = np.dtype([("hit", "<i4"), ("matches", "<i4")])
 SYMBOLS = [
     "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_db_build", "pgx_db_open",
     "pgx_db_from_fasta", "pgx_db_close", "pgx_db_num_seqs", "pgx_db_num_bases", "pgx_db_seq_id",
-    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped",
+    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust",
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
@@ -264,6 +264,10 @@ class Db(_Handle):
     def set_ungapped(self, flag=True):
         """`blastn -ungapped` for searches through this handle: stop after the ungapped stage (spec v1)."""
         _check(lib().pgx_db_set_ungapped(self.ptr, 1 if flag else 0))
+
+    def set_dust(self, flag=True):
+        """`blastn -dust no` (flag False) for searches through this handle."""
+        _check(lib().pgx_db_set_dust(self.ptr, 1 if flag else 0))
 
     def bind_taxonomy(self, tax):
         _check(lib().pgx_db_bind_taxonomy(self.ptr, tax.ptr))
@@ -461,9 +465,9 @@ def makeblastdb(infile, out):
     _check(lib().pgx_db_build(_b(infile), _b(out)))
 
 
-def blastn(query, db, out, outfmt=6, rank=0, world_size=1, ungapped=False):
-    """`blastn -query F -db DB -outfmt 6 -out O [-ungapped]` (reference README.md:96)."""
-    o = _BlastnOpts(_b(query), _b(db), _b(out), int(outfmt), rank, world_size, 1 if ungapped else 0)
+def blastn(query, db, out, outfmt=6, rank=0, world_size=1, ungapped=False, dust=True):
+    """`blastn -query F -db DB -outfmt 6 -out O [-ungapped] [-dust no]` (reference README.md:96)."""
+    o = _BlastnOpts(_b(query), _b(db), _b(out), int(outfmt), rank, world_size, 1 if ungapped else 0, 0 if dust else 1)
     _check(lib().pgx_blastn_run(C.byref(o)))
 
 

@@ -8,7 +8,7 @@
 
 int main(int argc, char **argv)
 {
-	pgx_blastn_opts o = { nullptr, nullptr, nullptr, 6, 0, 1, 0 };
+	pgx_blastn_opts o = { nullptr, nullptr, nullptr, 6, 0, 1, 0, 0 };
 	for (int i = 1; i < argc; i++)
 		if (!strcmp(argv[i], "-ungapped")) // blastn's own flag: ungapped alignments only (spec v1)
 			o.ungapped = 1;
@@ -19,6 +19,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "-outfmt")) o.outfmt = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-rank")) o.rank = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "-world_size")) o.world_size = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "-dust")) o.no_dust = !strcmp(argv[++i], "no"); // "yes" and "20 64 1" are the default
 		else if (!strcmp(argv[i], "-num_threads")) ++i; // accepted, the GPU does the work
 	}
 	if (!o.query_path || !o.db_prefix || !o.out_path) {

@@ -670,6 +670,7 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 	pgx_db *db = nullptr;
 	PGX_TRY(pgx_db_open(o->db_prefix, &db));
 	db->ungapped = o->ungapped != 0;
+	db->dust = o->no_dust == 0;
 	// (a rank outside [0, world_size) used to write an empty file and succeed)
 	if (o->world_size > 0 && (o->rank < 0 || o->rank >= o->world_size)) {
 		pgx_db_close(db);

@@ -352,6 +352,7 @@ struct WaveLds {
 	// subject found while filtering
 	uint32_t qp[kQueue], qmeta[kQueue], qsubj[kQueue], qs0[kQueue], qs1[kQueue];
 	uint32_t diag[2][2][kDiagSlots / 2]; // per read of the pair and strand: diagonals already owned by a queued candidate
+	uint64_t uwin[2][2][8];              // per read of the pair and strand: S3d window bits (positions whose 28 bases touch no masked base)
 	unsigned int n[2];                   // staged hits per read slot
 	unsigned int direct[2];              // hits that found the stage full and went straight to the overflow table
 };
@@ -439,11 +440,28 @@ __device__ __forceinline__ void emit_hit(WaveLds *st, int rs, const OutView &ov,
 	}
 }
 
+// S3d on dense window bits in memory: is any of the positions a .. b a window free of masked bases?
+__device__ __forceinline__ bool uwin_any(const uint64_t *uw, int a, int b)
+{
+	if (b < a)
+		return false;
+	for (int w = a >> 6; w <= (b >> 6); w++) {
+		uint64_t v = uw[w];
+		if (w == (a >> 6))
+			v &= ~0ull << (a & 63);
+		if (w == (b >> 6) && (b & 63) != 63)
+			v &= (2ull << (b & 63)) - 1ull;
+		if (v)
+			return true;
+	}
+	return false;
+}
+
 // One candidate = one (strand, probe position, posting).  `tested` says the index already proved that
 // this probe is the left-most one of its exact run (test 1 below).
 template <bool AMB, class Mask, class Emit>
-__device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, int L, uint32_t read, uint32_t woff,
-						   int strand, int qp, uint32_t p, bool tested, bool claimed, uint32_t s,
+__device__ __forceinline__ void process_candidate(const DbView &db, const uint64_t *rw, const uint64_t *ra, const uint64_t *uw, int L,
+						   uint32_t read, uint32_t woff, int strand, int qp, uint32_t p, bool tested, bool claimed, uint32_t s,
 						   uint32_t s_start, uint32_t s_end, Emit &emit, unsigned long long &n_runs)
 {
 	if (p + (uint32_t)kSeedK > s_end)
@@ -484,10 +502,17 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		// the diagonal is taken from the window bitmap, whichever probe got here first
 		if constexpr (Mask::kHasWindows) {
 			W = M.seed_windows();
+			if (uw) {
+#pragma unroll
+				for (int k = 0; k < Mask::kBits / 64; k++)
+					W.w[k] &= uw[k]; // S3d: windows that touch a masked base of the read seed nothing
+			}
 			run_start = Mask::win_first_ge(W, 0);
 		}
 		if (run_start >= D.hi)
 			return; // no exact run of 28 on this diagonal (the dealing-stage filter only bounds it)
+		if (uw)
+			run_start = M.last_lt(run_start) + 1; // (the first clean window may lie inside its run)
 		n_runs++;
 		if (PGX_DBG_STOP(db) == 5 || PGX_DBG_STOP(db) == 6)
 			return;
@@ -503,19 +528,32 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 		run_start = lm + 1;
 		if (re - run_start < kWord)
 			return;
-		n_runs++; // a >= 28 exact run reached through its left-most probe
-		if (PGX_DBG_STOP(db) == 5)
-			return;
-		// (3) only the first >= 28 run of a diagonal generates the diagonal's HSPs
+		// (3) only the first seed run of a diagonal generates the diagonal's HSPs; S3d: a run seeds only through a window
+		// that touches no masked base of the read
 		if constexpr (Mask::kHasWindows) {
 			W = M.seed_windows();
+			if (uw) {
+#pragma unroll
+				for (int k = 0; k < Mask::kBits / 64; k++)
+					W.w[k] &= uw[k];
+				if (Mask::win_first_ge(W, run_start) > re - kWord)
+					return;
+			}
+			n_runs++; // a seed run reached through its left-most probe
+			if (PGX_DBG_STOP(db) == 5)
+				return;
 			if (Mask::win_any_below(W, run_start))
 				return;
 		} else {
+			if (uw && !uwin_any(uw, run_start, re - kWord))
+				return;
+			n_runs++;
+			if (PGX_DBG_STOP(db) == 5)
+				return;
 			pos = D.lo;
 			while (pos < run_start) {
 				int m1 = M.first_ge(pos);
-				if (m1 - pos >= kWord)
+				if (m1 - pos >= kWord && (!uw || uwin_any(uw, pos, m1 - kWord)))
 					return;
 				pos = m1 + 1;
 			}
@@ -529,7 +567,10 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 	while (pos < D.hi) {
 		const int e = M.first_ge(pos);
 		const int len = e - pos;
-		if (len >= kWord && pos >= covered) {
+		bool seeds = len >= kWord && pos >= covered;
+		if constexpr (!Mask::kHasWindows)
+			seeds = seeds && (!uw || uwin_any(uw, pos, e - kWord));
+		if (seeds) {
 			int best = 0, cur = 0, bl = pos, nmm = 0, mm_best = 0;
 			int k = pos - 1; // a flagged position, or lo-1
 			typename Mask::Bwd cl = M.bwd_from(k);
@@ -613,9 +654,11 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				emit(h);
 			covered = br + 1;
 		}
-		if constexpr (Mask::kHasWindows)
+		if constexpr (Mask::kHasWindows) {
 			pos = Mask::win_first_ge(W, covered > e ? covered : e + 1); // next seed run (a run start)
-		else
+			if (uw && pos < D.hi)
+				pos = M.last_lt(pos) + 1; // (with S3d the first clean window may lie inside its run)
+		} else
 			pos = covered > e + 1 ? covered : e + 1;
 	}
 }
@@ -690,6 +733,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 			for (int k = 0; k < 2 * kDiagSlots / 64; k++)
 				(&st->diag[0][0][0])[k * 64 + lane] = kNoDiag;
 		}
+		// S3d: only reads with a masked base (a few per cent of random reads: a homopolymer of seven) carry window bits
+		const bool dustA = rd.dustwin_f && rd.dust_any[rA] != 0, dustB = rd.dustwin_f && hasB && rd.dust_any[rB] != 0;
+		if (DENSE && (dustA || dustB) && lane < 32) {
+			const int us = lane >> 4, ustr = (lane >> 3) & 1, uk = lane & 7;
+			const int uL = us ? LB : LA;
+			uint64_t v = 0;
+			if ((us ? dustB : dustA) && uk < (uL + 63) / 64)
+				v = (ustr ? rd.dustwin_r : rd.dustwin_f)[(us ? wB : wA) + uk];
+			st->uwin[us][ustr][uk] = v;
+		}
 		lds_fence();
 
 		// spill one read's staged hits to the overflow table in the middle of the work: it becomes fragmented
@@ -736,11 +789,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 					const uint64_t *a = strand ? rd.rc_amb : rd.fwd_amb;
 					ra = a ? a + cw0 : nullptr;
 				}
+				// S3d window bits of this candidate's read and strand: LDS copy (dense flags), or the words in memory
+				const uint64_t *uw = nullptr;
+				if (rs ? dustB : dustA)
+					uw = DENSE ? st->uwin[rs][strand] : (strand ? rd.dustwin_r : rd.dustwin_f) + cw0;
 				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh, db.gapped != 0); };
 				if (DENSE)
-					process_candidate<AMB, DenseMask<AMB, (NW > 0 ? NW : 3)>>(db, rw, ra, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, DenseMask<AMB, (NW > 0 ? NW : 3)>>(db, rw, ra, uw, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 				else
-					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
+					process_candidate<AMB, LazyMask<AMB>>(db, rw, ra, uw, cL, cr, cw0, strand, qp, p, tested, claimed, sj, s0, s1, emit, n_runs);
 			}
 			lds_fence();
 			// a read's stage more than half full in the middle of the work: the read becomes fragmented
@@ -1658,6 +1715,9 @@ static ReadsView reads_view(const pgx_reads *rd)
 	v.woff = rd->d_woff.data();
 	v.n = (uint32_t)rd->n;
 	v.list = nullptr;
+	v.dustwin_f = rd->has_dust ? rd->d_dustwin_f.data() : nullptr;
+	v.dustwin_r = rd->has_dust ? rd->d_dustwin_r.data() : nullptr;
+	v.dust_any = rd->has_dust ? rd->d_dust_any.data() : nullptr;
 	return v;
 }
 
@@ -1834,7 +1894,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		PGX_TRY(ws.piece_off.ensure(ns + 1));
 		PGX_TRY(ws.parent_start.ensure(n));
 	}
-	const ReadsView rv = reads_view(sr);
+	ReadsView rv = reads_view(sr);
+	if (!db->dust)
+		rv.dustwin_f = rv.dustwin_r = nullptr; // `-dust no`
 	const int grid = (int)std::min<uint64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock, 256ull * 8);
 
 	// capacities are guesses kept from earlier calls; every kernel checks them, the counters say at the end of the
@@ -2132,6 +2194,15 @@ int pgx_db_set_ungapped(pgx_db *db, int ungapped)
 		return fail(PGX_E_ARG, "pgx_db_set_ungapped: null argument");
 	std::lock_guard<std::mutex> lock(db->search_mu);
 	db->ungapped = ungapped != 0;
+	return 0;
+}
+
+int pgx_db_set_dust(pgx_db *db, int dust)
+{
+	if (!db)
+		return fail(PGX_E_ARG, "pgx_db_set_dust: null argument");
+	std::lock_guard<std::mutex> lock(db->search_mu);
+	db->dust = dust != 0;
 	return 0;
 }
 

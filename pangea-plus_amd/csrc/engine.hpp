@@ -35,6 +35,7 @@ struct pgx_db {
 	int64_t n_postings = 0;
 	std::shared_ptr<void> work; // classify.hip: the handle's search workspace (stream, tables, counters), made on first use
 	std::mutex search_mu;       // searches through one handle are serialised; different handles share nothing
+	bool dust = true;      // pgx_db_set_dust: `-dust no` switches the low-complexity mask of the reads off
 	bool ungapped = false; // pgx_db_set_ungapped: searches through this handle stop after the ungapped stage (spec v1)
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
 	// databases without ambiguity: 12-byte records {posting, database bases left of the 16-mer, bases right of it}, the
@@ -91,6 +92,11 @@ struct pgx_reads {
 	int64_t n_words = 0;
 	int32_t max_len = 0;
 	pgx::DevBuf<uint64_t> d_fwd, d_rc, d_fwd_amb, d_rc_amb;
+	// spec v2 S3d (dust.hip): per strand one bit per read position: the 28 bases from there on touch no base that DUST
+	// masks; 64 positions per word at the read's word offset; absent when no read of the batch has a masked base
+	bool has_dust = false;
+	pgx::DevBuf<uint64_t> d_dustwin_f, d_dustwin_r;
+	pgx::DevBuf<uint8_t> d_dust_any; // per read: it has a masked base (the others skip the window bits)
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
 	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the
 	// stretches between such runs (seqdb.hip: reads_build_pieces): `pieces` is a batch of its own, pieces of a read
@@ -216,6 +222,9 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text, int64_t first
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);
 
+// dust.hip
+int reads_dust(pgx_reads *rd);
+
 // classify.hip
 struct SearchCounters {
 	unsigned long long probes, postings, candidates, hits;
@@ -263,6 +272,8 @@ struct DbView {
 
 struct ReadsView {
 	const uint64_t *fwd, *rc, *fwd_amb, *rc_amb;
+	const uint64_t *dustwin_f, *dustwin_r; // S3d window bits per strand (null: no read of the batch is masked, or `-dust no`)
+	const uint8_t *dust_any;               // per read: has a masked base
 	const uint32_t *len, *woff;
 	uint32_t n;           // reads this launch works on
 	const uint32_t *list; // their ids (null: 0 .. n-1): a batch is searched class by class (flag words, ambiguity)

@@ -839,6 +839,8 @@ static int reads_finish(pgx_reads *rd)
 		PGX_HIP(hipGetLastError());
 	}
 	PGX_HIP(hipDeviceSynchronize());
+	if (!getenv("PGX_NO_DUST"))
+		PGX_TRY(reads_dust(rd));
 	return 0;
 }
 

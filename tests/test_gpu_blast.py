@@ -422,6 +422,75 @@ def test_reads_with_insertions_and_deletions(pg, oracle_bin, tmp_path, seed):
     assert _blast_text(pg, db, rd, tmp_path, "indel") == want.read_bytes()
 
 
+@pytest.mark.parametrize("seed", [8, 9])
+def test_low_complexity_reads_are_masked_for_seeding(pg, oracle_bin, tmp_path, seed):
+    """Spec v2, S3d (`-dust "20 64 1"`, BLAST+'s default): homopolymers, di- and tri-nucleotide repeats, AT-rich stretches
+    in reads and database; seeds inside masked stretches vanish, extensions run through them; `-dust no` switches it off.
+    Reads of 100-600 bases (dense flags in registers and the any-length path) and 1 400 bases."""
+    import random
+    rng = random.Random(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+    def lowc(n):
+        kind = rng.randrange(5)
+        if kind == 0:
+            return rng.choice("ACGT") * n
+        if kind == 1:
+            return (rng.choice(["AC", "GT", "AT", "CG", "AG"]) * n)[:n]
+        if kind == 2:
+            return ("".join(rng.choice("ACGT") for _ in range(3)) * n)[:n]
+        if kind == 3:
+            return "".join(rng.choice("AAAAAAT") for _ in range(n))
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    seqs = []
+    for i in range(80):
+        L = rng.choice([300, 800, 1600])
+        s = "".join(rng.choice("ACGT") for _ in range(L))
+        for _ in range(rng.choice([1, 2, 4])):
+            n = rng.choice([7, 9, 15, 30, 45, 70, 120])
+            p_ = rng.randrange(0, L - n)
+            s = s[:p_] + lowc(n) + s[p_ + n:]
+        if seqs and i % 3 == 0:
+            base = list(rng.choice(seqs))
+            for p_ in rng.sample(range(len(base)), len(base) // 40):
+                base[p_] = rng.choice("ACGT")
+            s = "".join(base)
+        seqs.append(s)
+    db = tmp_path / "lc.fa"
+    db.write_text("".join(">gi|%d|x|l%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    reads = []
+    for i in range(700):
+        s = rng.choice(seqs)
+        L = min(len(s), rng.choice([100, 150, 150, 250, 400, 600, 1400]))
+        o = rng.randrange(0, len(s) - L + 1)
+        w = list(s[o:o + L])
+        for p_ in rng.sample(range(L), rng.choice([0, 1, 2, L // 50])):
+            w[p_] = rng.choice("ACGTN")
+        if rng.random() < 0.3:
+            p_ = rng.randrange(1, L - 1)
+            if rng.random() < 0.5:
+                del w[p_:p_ + rng.choice([1, 2, 5])]
+            else:
+                w[p_:p_] = list(lowc(rng.choice([1, 3, 8])))
+        w = "".join(w)
+        if i % 2:
+            w = "".join(comp[c] for c in reversed(w))
+        reads.append(">c%d\n%s\n" % (i, w))
+    rd = tmp_path / "lc_reads.fa"
+    rd.write_text("".join(reads))
+    want, want_off = tmp_path / "lc_oracle.tsv", tmp_path / "lc_oracle_nodust.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want), "-num_threads", "8"], timeout=900)[0] == 0
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want_off), "-num_threads", "8",
+                    "-dust", "no"], timeout=900)[0] == 0
+    assert want.read_bytes() != want_off.read_bytes() and len(want.read_bytes()) > 20000
+    pg.makeblastdb(str(db), str(tmp_path / "lcdb"))
+    out = tmp_path / "lc.tsv"
+    pg.blastn(str(rd), str(tmp_path / "lcdb"), str(out))
+    assert out.read_bytes() == want.read_bytes()
+    pg.blastn(str(rd), str(tmp_path / "lcdb"), str(out), dust=False)
+    assert out.read_bytes() == want_off.read_bytes()
+
+
 def test_command_lines_with_the_reference_flags(workload, tmp_path):
     """`makeblastdb -in F -out P -dbtype nucl` (README.md:62) and `blastn -query F -db P -outfmt 6 -out O`
     (README.md:96) as executables, incl. the rank/world_size extension that replaces mpiblastn's partition."""
