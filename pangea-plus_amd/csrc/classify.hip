@@ -689,7 +689,7 @@ __device__ __forceinline__ void lds_fence()
 // drained together (160 candidates fill 64-lane drains far better than 80), each read staging its hits in
 // its own half of the stage.  Longer reads keep the wavefront to themselves.
 // LISTED: the launch works on the reads named by rd.list (one search class of a mixed batch) instead of 0 .. n-1
-template <bool AMB, int NW, bool LISTED>
+template <bool AMB, int NW, bool LISTED, bool DUST>
 __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_extend(DbView db, ReadsView rd, OutView ov,
 								      uint32_t *__restrict__ read_cnt,
 								      uint32_t *__restrict__ read_start)
@@ -734,8 +734,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				(&st->diag[0][0][0])[k * 64 + lane] = kNoDiag;
 		}
 		// S3d: only reads with a masked base (a few per cent of random reads: a homopolymer of seven) carry window bits
-		const bool dustA = rd.dustwin_f && rd.dust_any[rA] != 0, dustB = rd.dustwin_f && hasB && rd.dust_any[rB] != 0;
-		if (DENSE && (dustA || dustB) && lane < 32) {
+		// (DUST = the launch works on the class of reads that have one; a listed pair may still mix in its last wave)
+		const bool dustA = DUST && rd.dustwin_f && rd.dust_any[rA] != 0, dustB = DUST && rd.dustwin_f && hasB && rd.dust_any[rB] != 0;
+		if (DUST && DENSE && (dustA || dustB) && lane < 32) {
 			const int us = lane >> 4, ustr = (lane >> 3) & 1, uk = lane & 7;
 			const int uL = us ? LB : LA;
 			uint64_t v = 0;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 				}
 				// S3d window bits of this candidate's read and strand: LDS copy (dense flags), or the words in memory
 				const uint64_t *uw = nullptr;
-				if (rs ? dustB : dustA)
+				if (DUST && (rs ? dustB : dustA))
 					uw = DENSE ? st->uwin[rs][strand] : (strand ? rd.dustwin_r : rd.dustwin_f) + cw0;
 				auto emit = [&](const pgx_hit &hh) { emit_hit<RPW == 2>(st, rs, ov, hh, db.gapped != 0); };
 				if (DENSE)
@@ -1956,12 +1957,19 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			cvw.list = c.listed ? sr->d_class_list.data() + c.off : nullptr;
 			const int per_block = kWavesPerBlock * (c.words > 0 ? 2 : 1);
 			const dim3 g((unsigned)std::min<uint64_t>((cn + per_block - 1) / per_block, 256ull * 8)), b(64 * kWavesPerBlock);
-#define PGX_SEED_LAUNCH(A, W)                                                                                                      \
+#define PGX_SEED_LAUNCH2(A, W, D)                                                                                                  \
 	do {                                                                                                                       \
 		if (c.listed)                                                                                                      \
-			hipLaunchKernelGGL((k_seed_extend<A, W, true>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);                \
+			hipLaunchKernelGGL((k_seed_extend<A, W, true, D>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);             \
 		else                                                                                                               \
-			hipLaunchKernelGGL((k_seed_extend<A, W, false>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);               \
+			hipLaunchKernelGGL((k_seed_extend<A, W, false, D>), g, b, 0, st, dv, cvw, ov, rc_ptr, rs_ptr);            \
+	} while (0)
+#define PGX_SEED_LAUNCH(A, W)                                                                                                      \
+	do {                                                                                                                       \
+		if (c.dust && cvw.dustwin_f)                                                                                       \
+			PGX_SEED_LAUNCH2(A, W, true);                                                                              \
+		else                                                                                                               \
+			PGX_SEED_LAUNCH2(A, W, false);                                                                             \
 	} while (0)
 			if (c.amb && c.words == 3)
 				PGX_SEED_LAUNCH(true, 3);
@@ -1980,6 +1988,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			else
 				PGX_SEED_LAUNCH(false, 0);
 #undef PGX_SEED_LAUNCH
+#undef PGX_SEED_LAUNCH2
 		}
 		PGX_HIP(hipGetLastError());
 		trace_point("k_seed_extend");

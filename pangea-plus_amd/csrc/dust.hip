@@ -150,13 +150,16 @@ int reads_dust(pgx_reads *rd)
 			   rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr, rd->d_len.data(), rd->d_woff.data(), (uint32_t)n,
 			   d_mask.data(), d_any.data());
 	PGX_HIP(hipGetLastError());
-	std::vector<uint8_t> h_any(n);
+	std::vector<uint8_t> &h_any = rd->h_read_dust;
+	h_any.resize(n);
 	PGX_TRY(d_any.download(h_any.data(), n));
 	bool some = false;
 	for (size_t i = 0; i < n && !some; i++)
 		some = h_any[i] != 0;
-	if (!some)
+	if (!some) {
+		h_any.clear();
 		return 0; // no read of the batch has a masked base: the seed stage runs as without DUST
+	}
 	PGX_TRY(rd->d_dustwin_f.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	PGX_TRY(rd->d_dustwin_r.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, d_mask.data(), d_any.data(), rd->d_len.data(),

@@ -78,6 +78,7 @@ struct pgx_reads {
 	std::vector<uint32_t> name_len;
 	std::vector<uint32_t> h_len, h_woff;
 	std::vector<uint8_t> h_read_amb; // per read: holds an ambiguity letter (empty: none does)
+	std::vector<uint8_t> h_read_dust; // per read: holds a DUST-masked base (empty: none does)
 	// search classes (built once when the batch is made): reads are searched class by class -- flag words of a
 	// diagonal (3: <= 192 bases, 5: <= 320, 8: <= 512, 0: longer) x ambiguity letters -- so that a few long or
 	// N-holding reads do not slow down the rest.  One class without a list = the whole batch.
@@ -85,6 +86,7 @@ struct pgx_reads {
 		int amb, words;
 		uint32_t off, count;
 		bool listed;
+		int dust; // its reads have DUST-masked bases (S3d): the seed kernel variant that applies the window bits
 	};
 	std::vector<SearchClass> classes;
 	pgx::DevBuf<uint32_t> d_class_list;

@@ -786,28 +786,33 @@ static int reads_build_classes(pgx_reads *rd)
 	const size_t n = (size_t)rd->n;
 	rd->classes.clear();
 	const bool per_read_amb = rd->has_amb && rd->h_read_amb.size() == n;
+	const bool per_read_dust = rd->has_dust && rd->h_read_dust.size() == n;
 	bool uniform = true;
 	const int w0 = words_for(n ? rd->h_len[0] : (uint32_t)rd->max_len);
 	if (!rd->synthetic) // synthetic batches have one length and no ambiguity letters
 		for (size_t r = 0; r < n && uniform; r++)
 			uniform = words_for(rd->h_len[r]) == w0 && !(per_read_amb && rd->h_read_amb[r] != rd->h_read_amb[0]);
+	if (per_read_dust) // (a few per cent of random reads hold a homopolymer of seven: they get a class of their own)
+		for (size_t r = 0; r < n && uniform; r++)
+			uniform = rd->h_read_dust[r] == rd->h_read_dust[0];
 	if (uniform) {
 		const int a = rd->has_amb && (!per_read_amb || (n && rd->h_read_amb[0]));
-		rd->classes.push_back({ a, w0, 0u, (uint32_t)n, false });
+		rd->classes.push_back({ a, w0, 0u, (uint32_t)n, false, per_read_dust && n && rd->h_read_dust[0] ? 1 : 0 });
 		return 0;
 	}
-	std::vector<uint32_t> ids[8];
+	std::vector<uint32_t> ids[16];
 	for (size_t r = 0; r < n; r++) {
 		const int a = rd->has_amb && (!per_read_amb || rd->h_read_amb[r]);
+		const int d = per_read_dust && rd->h_read_dust[r];
 		const int w = words_for(rd->h_len[r]);
-		ids[a * 4 + (w == 3 ? 0 : w == 5 ? 1 : w == 8 ? 2 : 3)].push_back((uint32_t)r);
+		ids[(d * 2 + a) * 4 + (w == 3 ? 0 : w == 5 ? 1 : w == 8 ? 2 : 3)].push_back((uint32_t)r);
 	}
 	std::vector<uint32_t> all;
 	all.reserve(n);
 	static const int kWords[4] = { 3, 5, 8, 0 };
-	for (int c = 0; c < 8; c++)
+	for (int c = 0; c < 16; c++)
 		if (!ids[c].empty()) {
-			rd->classes.push_back({ c / 4, kWords[c % 4], (uint32_t)all.size(), (uint32_t)ids[c].size(), true });
+			rd->classes.push_back({ (c / 4) & 1, kWords[c % 4], (uint32_t)all.size(), (uint32_t)ids[c].size(), true, c / 8 });
 			all.insert(all.end(), ids[c].begin(), ids[c].end());
 		}
 	PGX_TRY(rd->d_class_list.alloc(all.size()));
@@ -816,7 +821,6 @@ static int reads_build_classes(pgx_reads *rd)
 
 static int reads_finish(pgx_reads *rd)
 {
-	PGX_TRY(reads_build_classes(rd));
 	// d_fwd (and d_fwd_amb) are filled; build offsets/lengths on device and the rc strand
 	PGX_TRY(rd->d_len.alloc((size_t)rd->n));
 	PGX_TRY(rd->d_len.upload(rd->h_len.data(), (size_t)rd->n));
@@ -826,7 +830,7 @@ static int reads_finish(pgx_reads *rd)
 	}
 	PGX_TRY(rd->d_rc.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	if (rd->n == 0)
-		return 0;
+		return reads_build_classes(rd);
 	int grid = (int)std::min<int64_t>(rd->n, 65535 * 16);
 	int block = rd->max_len > 2048 ? 256 : 64;
 	hipLaunchKernelGGL(k_revcomp, dim3(grid), dim3(block), 0, 0, rd->d_fwd.data(), rd->d_woff.data(),
@@ -841,7 +845,7 @@ static int reads_finish(pgx_reads *rd)
 	PGX_HIP(hipDeviceSynchronize());
 	if (!getenv("PGX_NO_DUST"))
 		PGX_TRY(reads_dust(rd));
-	return 0;
+	return reads_build_classes(rd); // (after the DUST pass: reads with masked bases are a search class of their own)
 }
 
 
