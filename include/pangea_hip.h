@@ -110,10 +110,10 @@ typedef struct {
 	const char *db_prefix;     /* -D (with or without the ".index" suffix) */
 	const char *out_path;      /* -o */
 	const char *unmapped_path; /* -u, may be NULL */
-	int match_mode;            /* -M, only 4 (best hits) */
+	int match_mode;            /* -M 4 (best hits, the reference's call) or 0 / 1 / 2 (exactly that many mismatches; reads <= 256 bases) */
 	int repeat_mode;           /* -r 0|1|2, default 1 */
 	int max_n;                 /* -n, default 5 */
-	int report_id;             /* -t */
+	int report_id;             /* -t: the read's 0-based ordinal in the file instead of its name */
 } pgx_soap_opts;
 int pgx_soap_index(const char *fasta_path); /* writes <fasta>.index.pgxdb */
 int pgx_soap_run(const pgx_soap_opts *opts);

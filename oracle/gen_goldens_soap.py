@@ -130,7 +130,23 @@ def generate(scratch, gold, soap_dir, ref_root="/root/reference"):
         subprocess.run([soap, "-a", "reads.fa", "-D", "ref.fa.index", "-o", f"out_{tag}.txt", "-u",
                         f"unmapped_{tag}.txt", "-p", "1", "-M", "4", "-r", r], cwd=work, check=True, timeout=600,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for n in ("ref.fa", "reads.fa", "out_r2.txt", "out_r1.txt", "unmapped_r2.txt"):
+    # -M 0 / 1 / 2 (soap.man:73-82) on the reads of at most 256 bases: for longer reads the mode applies to the first
+    # 256 bases only (-l, soap.man:60-63), which is not restated
+    short = [(n, s_) for n, s_ in reads if len(s_) <= 256]
+    with open(os.path.join(work, "reads_short.fa"), "w") as f:
+        for n, s_ in short:
+            f.write(f">{n}\n{s_}\n")
+    for m in ("0", "1", "2"):
+        subprocess.run([soap, "-a", "reads_short.fa", "-D", "ref.fa.index", "-o", f"out_M{m}.txt", "-u", f"unmapped_M{m}.txt", "-p", "1",
+                        "-M", m, "-r", "2"], cwd=work, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([soap, "-a", "reads_short.fa", "-D", "ref.fa.index", "-o", "out_t.txt", "-p", "1", "-M", "4", "-r", "2", "-t"], cwd=work,
+                   check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)  # -t: ordinals instead of names
+    import gzip
+    for n in ("ref.fa", "reads.fa", "out_r2.txt", "out_r1.txt", "unmapped_r2.txt", "reads_short.fa", "unmapped_M0.txt", "unmapped_M1.txt",
+              "unmapped_M2.txt"):
         shutil.copy(os.path.join(work, n), os.path.join(out, n))
+    for tag in ("M0", "M1", "M2", "t"):
+        with open(os.path.join(work, f"out_{tag}.txt"), "rb") as a, gzip.GzipFile(os.path.join(out, f"out_{tag}.txt.gz"), "wb", mtime=0) as b:
+            shutil.copyfileobj(a, b)
     rows = sum(1 for _ in open(os.path.join(out, "out_r2.txt")))
     print(f"soap: {len(reads)} reads, {rows} rows (-r 2)")

@@ -42,6 +42,9 @@ static int run_soap(int argc, char **argv)
 	const char *o = arg_of(argc, argv, "-o", NULL), *u = arg_of(argc, argv, "-u", NULL);
 	o_soap_opts opt = { atoi(arg_of(argc, argv, "-M", "4")), atoi(arg_of(argc, argv, "-r", "1")),
 			    atoi(arg_of(argc, argv, "-n", "5")), 0 };
+	for (int i = 1; i < argc; i++)
+		if (strcmp(argv[i], "-t") == 0)
+			opt.id_only = 1;
 	if (!a || !D || !o) {
 		fprintf(stderr, "usage: soap -a reads.fa -D ref.fa.index -o out\n");
 		return 1;

@@ -91,8 +91,8 @@ static void format_row(obuf *out, const char *name, const uint8_t *rd, int32_t L
 int o_soap_files(const char *reads_fa, const char *ref_fa, const char *out_path, const char *unmapped_or_null,
 		 const o_soap_opts *opt)
 {
-	if (opt->match_mode != 4)
-		return -2; /* only -M 4 (the reference's documented call) is restated */
+	if (opt->match_mode != 4 && (opt->match_mode < 0 || opt->match_mode > 2))
+		return -2; /* -M 4 (the reference's documented call, README.md:134) and -M 0 / 1 / 2 (soap.man:73-82) */
 	o_seqset ref, reads;
 	if (o_seqset_read_fasta(&ref, ref_fa) < 0)
 		return -1;
@@ -241,10 +241,16 @@ int o_soap_files(const char *reads_fa, const char *ref_fa, const char *out_path,
 				}
 			}
 		}
+		/* -M 4: the placements with the fewest mismatches; -M 0 / 1 / 2 (observed on the ELF): the placements with
+		 * EXACTLY that many, whether or not a better one exists */
 		int best = 3;
-		for (size_t x = 0; x < nh; x++)
-			if (hits[x].nmis < best)
-				best = hits[x].nmis;
+		if (opt->match_mode == 4) {
+			for (size_t x = 0; x < nh; x++)
+				if (hits[x].nmis < best)
+					best = hits[x].nmis;
+		} else {
+			best = opt->match_mode;
+		}
 		size_t nbest = 0;
 		for (size_t x = 0; x < nh; x++)
 			if (hits[x].nmis == best)
@@ -254,8 +260,13 @@ int o_soap_files(const char *reads_fa, const char *ref_fa, const char *out_path,
 		if (nbest > 0 && !(opt->repeat == 0 && nbest > 1)) {
 			size_t lim = opt->repeat == 2 ? nbest : 1;
 			for (size_t x = 0; x < lim; x++)
-				format_row(&out, name, hits[x].strand ? rv : fw, L, &hits[x], (int)nbest, &ref,
+			{
+				/* -t (soap.man:48): the read's 0-based ordinal in the file instead of its name (observed on the ELF) */
+				char idn[32];
+				snprintf(idn, sizeof idn, "%lld", (long long)ri);
+				format_row(&out, opt->id_only ? idn : name, hits[x].strand ? rv : fw, L, &hits[x], (int)nbest, &ref,
 					   opt->repeat);
+			}
 			printed = 1;
 		}
 		if (!printed && !(nbest > 1)) {

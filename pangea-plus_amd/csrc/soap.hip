@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_soap_search(SoapView db, const uint64_t
 						     const uint32_t *__restrict__ woff, const uint8_t *__restrict__ skip,
 						     uint32_t n_reads, SoapHit *__restrict__ hits, unsigned long long cap,
 						     unsigned long long *__restrict__ hit_count, uint32_t *__restrict__ best_nmis,
-						     uint32_t *__restrict__ n_best)
+						     uint32_t *__restrict__ n_best, int mode)
 {
 	const int lane = threadIdx.x & 63;
 	for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n_reads; r += gridDim.x * 4) {
@@ -217,7 +217,12 @@ __global__ __launch_bounds__(256) void k_soap_search(SoapView db, const uint64_t
 				c0 = __shfl(c0, 0);
 				c1 = __shfl(c1, 0);
 				c2 = __shfl(c2, 0);
-				best = c0 ? 0u : (c1 ? 1u : (c2 ? 2u : 3u));
+				// -M 4: the fewest mismatches any placement has; -M 0 / 1 / 2 (soap.man:73-82, observed on the ELF):
+				// the placements with exactly that many, whether or not a better one exists
+				if (mode == 4)
+					best = c0 ? 0u : (c1 ? 1u : (c2 ? 2u : 3u));
+				else
+					best = (mode == 0 ? c0 : (mode == 1 ? c1 : c2)) ? (uint32_t)mode : 3u;
 				if (lane == 0) {
 					best_nmis[r] = best;
 					n_best[r] = best == 0 ? c0 : (best == 1 ? c1 : (best == 2 ? c2 : 0u));
@@ -302,10 +307,8 @@ int pgx_soap_run(const pgx_soap_opts *o)
 {
 	if (!o || !o->reads_path || !o->db_prefix || !o->out_path)
 		return fail(PGX_E_ARG, "soap: -a, -D and -o are required");
-	if (o->match_mode != 4)
-		return fail(PGX_E_ARG, "soap: only -M 4 (best hits) is implemented");
-	if (o->report_id)
-		return fail(PGX_E_ARG, "soap: -t is not implemented");
+	if (o->match_mode != 4 && (o->match_mode < 0 || o->match_mode > 2))
+		return fail(PGX_E_ARG, "soap: -M must be 0, 1, 2 or 4");
 	if (o->repeat_mode < 0 || o->repeat_mode > 2)
 		return fail(PGX_E_ARG, "soap: -r must be 0, 1 or 2");
 	PGX_TRY(require_device());
@@ -339,6 +342,14 @@ int pgx_soap_run(const pgx_soap_opts *o)
 	pgx_reads *rd = nullptr;
 	std::vector<uint32_t> nn;
 	rc = reads_from_fasta_ex(o->reads_path, 0, -1, true, &nn, &rd);
+	if (rc == 0 && o->match_mode != 4 && rd->max_len > 256) {
+		// for reads above -l (256) the ELF applies -M 0 / 1 / 2 to the first 256 bases only: not restated
+		const int longest = (int)rd->max_len;
+		pgx_reads_close(rd);
+		pgx_db_close(db);
+		return fail(PGX_E_LIMIT, "soap: -M %d is implemented for reads of at most 256 bases (this file holds one of %d)", o->match_mode,
+			    longest);
+	}
 	std::string out, unm;
 	if (rc == 0) {
 		const size_t n = (size_t)rd->n;
@@ -381,7 +392,7 @@ int pgx_soap_run(const pgx_soap_opts *o)
 			const int grid = (int)std::min<uint64_t>((n + 3) / 4, 2048);
 			hipLaunchKernelGGL(k_soap_search, dim3(grid), dim3(256), 0, 0, v, rd->d_fwd.data(), rd->d_rc.data(),
 					   rd->d_len.data(), rd->d_woff.data(), d_skip.data(), (uint32_t)n, d_hits.data(),
-					   (unsigned long long)cap, d_count.data(), d_best.data(), d_nbest.data());
+					   (unsigned long long)cap, d_count.data(), d_best.data(), d_nbest.data(), o->match_mode);
 			if (hipGetLastError() != hipSuccess) {
 				rc = fail(PGX_E_NODEVICE, "k_soap_search launch failed");
 				break;
@@ -423,8 +434,8 @@ int pgx_soap_run(const pgx_soap_opts *o)
 				if (nb > 0 && !(o->repeat_mode == 0 && nb > 1)) {
 					const size_t lim = o->repeat_mode == 2 ? he - hp : 1;
 					for (size_t x = 0; x < lim && hp + x < he; x++)
-						soap_row(out, rd->name_of(r), (hv[hp + x].strand_nmis >> 8) ? rv : fw, hv[hp + x], nb, db,
-							 o->repeat_mode);
+						soap_row(out, o->report_id ? std::to_string(r) : rd->name_of(r), // -t: the read's 0-based ordinal in the file
+							 (hv[hp + x].strand_nmis >> 8) ? rv : fw, hv[hp + x], nb, db, o->repeat_mode);
 					printed = true;
 				}
 				if (!printed && nb <= 1) {

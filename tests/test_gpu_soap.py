@@ -57,6 +57,36 @@ def test_soap_rows_equal_the_reference_binary(pg, gold, oracle_bin, tmp_path):
             assert a == b
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_soap_match_modes_equal_the_reference_binary(pg, gold, oracle_bin, tmp_path, mode):
+    """`soap -M 0 / 1 / 2` (soap.man:73-82): the placements with exactly that many mismatches, as the closed ELF printed
+    them for the reads of at most 256 bases (sets per read, the unmapped list byte for byte), and the oracle's bytes."""
+    import gzip
+    g = os.path.join(gold, "soap")
+    ref = tmp_path / "ref.fa"
+    ref.write_bytes(open(os.path.join(g, "ref.fa"), "rb").read())
+    pg.soap_index(str(ref))
+    out, unm, want = tmp_path / "m.txt", tmp_path / "u.txt", tmp_path / "want.txt"
+    want.write_bytes(gzip.open(os.path.join(g, "out_M%d.txt.gz" % mode), "rb").read())
+    pg.soap(os.path.join(g, "reads_short.fa"), str(ref) + ".index", str(out), u=str(unm), M=mode, r=2)
+    assert rows(out) == rows(want) and len(rows(out)) > 90
+    assert unm.read_bytes() == open(os.path.join(g, "unmapped_M%d.txt" % mode), "rb").read()
+    o = tmp_path / "o.txt"
+    assert run_cmd([oracle_bin, "soap", "-a", os.path.join(g, "reads_short.fa"), "-D", str(ref) + ".index", "-o", str(o), "-r", "2",
+                    "-M", str(mode)])[0] == 0
+    assert out.read_bytes() == o.read_bytes()
+    if mode == 0:
+        # -t (soap.man:48): the read's 0-based ordinal in the file instead of its name
+        want.write_bytes(gzip.open(os.path.join(g, "out_t.txt.gz"), "rb").read())
+        pg.soap(os.path.join(g, "reads_short.fa"), str(ref) + ".index", str(out), M=4, r=2, t=True)
+        assert rows(out) == rows(want)
+    # reads above 256 bases: the mode would apply to their first 256 bases only (-l): refused, not guessed
+    from pangea_plus_amd import _capi
+    with pytest.raises(_capi.PangeaError) as e:
+        pg.soap(os.path.join(g, "reads.fa"), str(ref) + ".index", str(out), M=mode, r=2)
+    assert e.value.status == -7
+
+
 @pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_SOAP_SEEDS", "3").split(",")])
 def test_soap_short_reads_and_seeded_mismatches_match_oracle(pg, oracle_bin, tmp_path, seed):
     import random

@@ -46,6 +46,19 @@ def test_soap_mode_matches_reference_binary(gold, oracle_bin, tmp_path):
             assert a == b
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_soap_match_modes_match_reference_binary(gold, oracle_bin, tmp_path, mode):
+    import gzip
+    g = os.path.join(gold, "soap")
+    out, unm, want = tmp_path / "m.txt", tmp_path / "u.txt", tmp_path / "want.txt"
+    want.write_bytes(gzip.open(os.path.join(g, "out_M%d.txt.gz" % mode), "rb").read())
+    rc, _, _ = run_cmd([oracle_bin, "soap", "-a", os.path.join(g, "reads_short.fa"), "-D", os.path.join(g, "ref.fa.index"), "-o", str(out),
+                        "-u", str(unm), "-r", "2", "-M", str(mode)])
+    assert rc == 0
+    assert soap_rows(str(out)) == soap_rows(str(want))
+    assert unm.read_bytes() == open(os.path.join(g, "unmapped_M%d.txt" % mode), "rb").read()
+
+
 # ---------------------------------------------------------------- BLAST mode brute force
 def read_fa(p):
     out = []
