@@ -263,6 +263,22 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
  * (Consensus:40-46); NULL, "" and "0" mean "not given" (Perl truth) */
 int pgx_classify_consensus_tri(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, const char *soap_stream_path,
 			       pgx_hits **hits_out, pgx_consensus_rec *out, int64_t cap);
+/* ---- opt-in extension: a real three-way vote, spec "pgx-vote3 v1".  NOT reference behaviour: the
+ * reference's Consensus opens the SOAP table and never reads it (Consensus_BLAST_SOAP_RDP-1.1.pl:40-46).  Per read with an
+ * RDP line: B = lineage of its first BLAST row (best hit), S = lineage of its first row in the SOAP table `soap_path`
+ * (soap.man: column 1 read, column 8 reference id), R = the RDP assignment; rank k is agreed when two of the three names
+ * are equal and not empty; the record is the longest prefix of agreed ranks. */
+typedef struct {
+	int32_t depth;    /* ranks agreed from the domain down (0..7); -1: the read has no RDP line */
+	uint32_t name[7]; /* token id of the agreed name per rank (text: pgx_vote3_format) */
+	uint8_t votes[7]; /* 2 or 3 per agreed rank */
+	uint8_t pad;
+} pgx_vote_rec;
+int pgx_vote3_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_rdp *rdp, const char *soap_path,
+		    pgx_vote_rec *out, int64_t cap);
+/* "<read>\t[0]Name;[1]Name;...\t<depth>\t<votes as digits>\n" per read with an RDP line, malloc'd */
+int pgx_vote3_format(const pgx_db *db, const pgx_reads *reads, const pgx_vote_rec *recs, int64_t n, char **text, size_t *len);
+
 /* consensus text ("<hit line with lineage>\n#Matches found: N\n" per read), malloc'd */
 int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
 			 const pgx_consensus_rec *recs, int64_t n, char **text, size_t *len);

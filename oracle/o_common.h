@@ -93,6 +93,9 @@ int o_taxcollect_buf(const o_taxdb *db, const char *in, size_t in_len, obuf *out
 int o_consensus_buf(const char *blast, size_t blast_len, const char *rdp, size_t rdp_len,
 		    obuf *out, obuf *log);
 int o_consensus_file(const char *b, const char *r, const char *s_or_null, const char *o, obuf *log);
+/* opt-in extension "pgx-vote3 v1" (o_consensus.c): majority of BLAST top hit, SOAP best hit and RDP per rank */
+int o_vote3_buf(const char *blast_class, size_t bl, const char *rdp, size_t rl, const char *soap_class, size_t sl, obuf *out);
+int o_vote3_file(const char *blast_class, const char *rdp, const char *soap_class, const char *out_path);
 
 #ifdef __cplusplus
 }

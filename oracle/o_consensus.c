@@ -344,3 +344,164 @@ int o_consensus_file(const char *b, const char *r, const char *s_or_null, const 
 	free(rb);
 	return rc;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Three-way vote -- an OPT-IN EXTENSION, not reference behaviour: the reference's Consensus opens the
+ * SOAP stream and never reads it (Consensus_BLAST_SOAP_RDP-1.1.pl:40-46).  Spec "pgx-vote3 v1":
+ *   per read of the RDP stream, three lineages as (rank index 0..6 -> name): B = the lineage of the read's FIRST row in the
+ *   BLAST table after taxcollector (the best hit, S5 order); S = the same for the read's first row in the SOAP table
+ *   after taxcollector; R = the RDP assignment with the script's name cleaning (Consensus:159-160) and rank names
+ *   (Consensus:64-72).  Lineages are tokenised as the script does (Consensus:116-122); a rank's name is the first pair
+ *   that carries its tag.  Rank k is AGREED when two of the three names are equal and not empty (B = S, else B = R,
+ *   else S = R); the consensus is the longest prefix of agreed ranks.
+ *   One line per RDP read: name, "[k]Name;" for the agreed prefix, its length, the votes per rank as digits.
+ */
+typedef struct {
+	sv name[7];
+} lin7;
+
+static void lin_from_lineage(sv tax, lin7 *l)
+{
+	sv tok[MAXTOK];
+	int n = lineage_tokens(tax, tok, MAXTOK);
+	memset(l, 0, sizeof *l);
+	for (int a = 0; a + 1 < n; a += 2) {
+		int k = blast_rank_index(tok[a]);
+		if (k >= 0 && l->name[k].p == NULL)
+			l->name[k] = tok[a + 1];
+	}
+}
+
+/* first row of every read in a taxcollector table: read -> lineage (column 2); rows of a read are consecutive */
+typedef struct {
+	sv read, lineage;
+} first_row;
+
+static size_t first_rows(const char *t, size_t len, first_row **out)
+{
+	size_t n = 0, cap = 1024, s = 0;
+	first_row *v = (first_row *)malloc(cap * sizeof *v);
+	while (s < len) {
+		const char *nl = (const char *)memchr(t + s, '\n', len - s);
+		size_t e = nl ? (size_t)(nl - t) : len;
+		sv f[4];
+		int nf = split_tabs(t + s, e - s, f, 4);
+		if (nf >= 2 && (n == 0 || !sv_eq(v[n - 1].read, f[0]))) {
+			if (n == cap) {
+				cap *= 2;
+				v = (first_row *)realloc(v, cap * sizeof *v);
+			}
+			v[n].read = f[0];
+			v[n].lineage = f[1];
+			n++;
+		}
+		s = e + 1;
+	}
+	*out = v;
+	return n;
+}
+
+static const first_row *find_row(const first_row *v, size_t n, sv read, size_t *cursor)
+{
+	/* both tables follow the read order of the RDP stream: walk forward from the cursor, else search everything */
+	for (size_t i = *cursor; i < n; i++)
+		if (sv_eq(v[i].read, read)) {
+			*cursor = i + 1;
+			return &v[i];
+		}
+	for (size_t i = 0; i < *cursor && i < n; i++)
+		if (sv_eq(v[i].read, read))
+			return &v[i];
+	return NULL;
+}
+
+int o_vote3_buf(const char *blast_class, size_t bl, const char *rdp, size_t rl, const char *soap_class, size_t sl, obuf *out)
+{
+	first_row *bv = NULL, *svv = NULL;
+	size_t bn = first_rows(blast_class, bl, &bv), sn = first_rows(soap_class, sl, &svv), bc = 0, sc = 0, s = 0;
+	static const char kFive[] = "\t\t\t\t\t";
+	while (s < rl) {
+		const char *nl = (const char *)memchr(rdp + s, '\n', rl - s);
+		size_t e = nl ? (size_t)(nl - rdp) : rl;
+		const char *line = rdp + s;
+		size_t len = e - s;
+		s = e + 1;
+		const char *five = NULL;
+		for (size_t i = 0; i + 5 <= len; i++)
+			if (memcmp(line + i, kFive, 5) == 0) {
+				five = line + i;
+				break;
+			}
+		sv read = { line, five ? (size_t)(five - line) : len };
+		lin7 B, S, R;
+		char clean[7][256];
+		memset(&B, 0, sizeof B);
+		memset(&S, 0, sizeof S);
+		memset(&R, 0, sizeof R);
+		const first_row *fb = find_row(bv, bn, read, &bc), *fs = find_row(svv, sn, read, &sc);
+		if (fb)
+			lin_from_lineage(fb->lineage, &B);
+		if (fs)
+			lin_from_lineage(fs->lineage, &S);
+		if (five) {
+			sv f[64];
+			int nf = split_tab1(five + 5, len - read.n - 5, f, 64);
+			for (int k = 0; k + 1 < nf; k += 3) {
+				int ri = rdp_rank_index(f[k + 1]);
+				if (ri >= 0 && R.name[ri].p == NULL) {
+					size_t cn = clean_rdp_name(f[k].n < 255 ? f[k] : (sv){ f[k].p, 255 }, clean[ri]);
+					R.name[ri].p = clean[ri];
+					R.name[ri].n = cn;
+				}
+			}
+		}
+		obuf_put(out, read.p, read.n);
+		obuf_puts(out, "\t");
+		char votes[8];
+		int depth = 0;
+		for (int k = 0; k < 7; k++) {
+			sv b = B.name[k], ss = S.name[k], r = R.name[k], w = { NULL, 0 };
+			int v = 0;
+			if (b.n && ss.n && sv_eq(b, ss)) {
+				w = b;
+				v = 2 + (r.n && sv_eq(r, b));
+			} else if (b.n && r.n && sv_eq(b, r)) {
+				w = b;
+				v = 2;
+			} else if (ss.n && r.n && sv_eq(ss, r)) {
+				w = ss;
+				v = 2;
+			}
+			if (!v)
+				break;
+			obuf_printf(out, "[%d]", k);
+			obuf_put(out, w.p, w.n);
+			obuf_puts(out, ";");
+			votes[depth++] = (char)('0' + v);
+		}
+		votes[depth] = 0;
+		obuf_printf(out, "\t%d\t%s\n", depth, votes);
+	}
+	free(bv);
+	free(svv);
+	return 0;
+}
+
+int o_vote3_file(const char *blast_class, const char *rdp, const char *soap_class, const char *out_path)
+{
+	size_t bl = 0, rl = 0, sl = 0;
+	char *b = o_read_file(blast_class, &bl), *r = o_read_file(rdp, &rl), *s = o_read_file(soap_class, &sl);
+	int rc = -1;
+	if (b && r && s) {
+		obuf out;
+		obuf_init(&out);
+		o_vote3_buf(b, bl, r, rl, s, sl, &out);
+		rc = obuf_write_file(&out, out_path);
+		obuf_free(&out);
+	}
+	free(b);
+	free(r);
+	free(s);
+	return rc;
+}

@@ -103,5 +103,12 @@ int main(int argc, char **argv)
 		return run_taxcollector(argc - 1, argv + 1);
 	if (strcmp(verb, "consensus") == 0)
 		return run_consensus(argc - 1, argv + 1);
+	if (strcmp(verb, "vote3") == 0) { /* vote3 BLAST_CLASS RDP SOAP_CLASS OUT: the opt-in three-way vote (pgx-vote3 v1) */
+		if (argc != 6) {
+			fprintf(stderr, "usage: pgx_oracle vote3 blast_class.tsv rdp.txt soap_class.tsv out.txt\n");
+			return 2;
+		}
+		return o_vote3_file(argv[2], argv[3], argv[4], argv[5]) < 0 ? 3 : 0;
+	}
 	return o_classify_main(argc - 1, argv + 1);
 }

@@ -81,6 +81,7 @@ class _SoapOpts(C.Structure):
 HIT_DTYPE = np.dtype([("read", "<i4"), ("subject", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"),
                       ("send", "<i4"), ("score", "<i4"), ("mismatch", "<u2"), ("gapopen", "<u2")])
 REC_DTYPE = np.dtype([("hit", "<i4"), ("matches", "<i4")])
+VOTE_DTYPE = np.dtype([("depth", "<i4"), ("name", "<u4", (7,)), ("votes", "u1", (7,)), ("pad", "u1")])
 
 # every symbol include/pangea_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -93,7 +94,7 @@ SYMBOLS = [
     "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_write_fasta", "pgx_rdp_write_file", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
-    "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri",
+    "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
     "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather",
 ]
 
@@ -129,6 +130,8 @@ def _declare(L):
     sig("pgx_consensus_batch", C.c_int, [V, V, V, V, I64])
     sig("pgx_classify_consensus", C.c_int, [V, V, V, V, V, I64])
     sig("pgx_classify_consensus_tri", C.c_int, [V, V, V, C.c_char_p, V, V, I64])
+    sig("pgx_vote3_batch", C.c_int, [V, V, V, V, C.c_char_p, V, I64])
+    sig("pgx_vote3_format", C.c_int, [V, V, V, I64, V, V])
     sig("pgx_consensus_format", C.c_int, [V, V, V, V, I64, V, V])
     sig("pgx_tax_lineage_batch", C.c_int, [V, V, I64, V, V, V])
     sig("pgx_megaclust_file", C.c_int, [V, V])
@@ -421,6 +424,16 @@ def classify_consensus(db, reads, rdp, want_records=True, want_hits=True, soap=N
         _check(lib().pgx_classify_consensus_tri(db.ptr, reads.ptr, rdp.ptr, _b(soap), C.byref(hp) if want_hits else None,
                                                 recs.ctypes.data if want_records else None, n))
     return (Hits(hp) if want_hits else None), recs
+
+
+def vote3(db, reads, hits, rdp, soap):
+    """Opt-in three-way vote (pgx-vote3 v1): (records, text).  `soap` = path of the SOAP table of the same reads."""
+    n = len(reads)
+    recs = np.zeros(n, dtype=VOTE_DTYPE)
+    _check(lib().pgx_vote3_batch(db.ptr, reads.ptr, hits.ptr, rdp.ptr, _b(soap), recs.ctypes.data, n))
+    txt, ln = C.c_void_p(), C.c_size_t()
+    _check(lib().pgx_vote3_format(db.ptr, reads.ptr, recs.ctypes.data, n, C.byref(txt), C.byref(ln)))
+    return recs, _take_text(txt.value, ln.value)
 
 
 def consensus_format(db, reads, hits, recs):

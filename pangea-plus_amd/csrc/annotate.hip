@@ -876,6 +876,186 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------ three-way vote (opt-in)
+// SURVEY 8(f) row 4, spec "pgx-vote3 v1" (restated by the checker in oracle/o_consensus.c): NOT reference behaviour -- the
+// reference's Consensus opens the SOAP table and never reads it (Consensus_BLAST_SOAP_RDP-1.1.pl:40-46); this is what
+// the tool's name promises.  Per read that has an RDP line, three lineages as (rank 0..6 -> name): B = the read's first
+// row of the BLAST table (its best hit), S = the read's first row of the SOAP table, R = the RDP assignment; names are
+// the token ids the Consensus comparison uses (same tokeniser, same cleaning).  A rank is agreed when two of the three
+// names are equal and not empty (B = S, else B = R, else S = R); the result is the longest prefix of agreed ranks.
+static_assert(sizeof(pgx_vote_rec) == 40, "pgx_vote_rec layout");
+
+__global__ void k_vote3(const pgx_hit *__restrict__ hits, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt,
+			const int32_t *__restrict__ soap_subj, const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ tok_off,
+			const uint32_t *__restrict__ tok, const int8_t *__restrict__ tok_rank, const uint32_t *__restrict__ rdp_off,
+			const uint32_t *__restrict__ rdp_code, const uint8_t *__restrict__ rdp_present, uint32_t n,
+			pgx_vote_rec *__restrict__ out)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n)
+		return;
+	uint32_t nm[3][7];
+	for (int c = 0; c < 3; c++)
+		for (int k = 0; k < 7; k++)
+			nm[c][k] = 0u;
+	auto lineage_of = [&](int32_t subject, uint32_t (&dst)[7]) { // a rank's name is its FIRST pair, empty or not
+		if (subject < 0)
+			return;
+		uint32_t seen = 0u;
+		const uint32_t *rec = pairs + 16ull * (uint32_t)subject;
+		const uint32_t np = rec[0] >> 16;
+		if (np != 0xFFFFu) {
+			for (uint32_t a = 0; a < np; a++) {
+				const uint32_t pr = rec[1 + a], rk = pr & 7u;
+				if (rk >= 1 && !(seen >> rk & 1u)) {
+					dst[rk - 1] = pr >> 3;
+					seen |= 1u << rk;
+				}
+			}
+		} else { // more pairs than the record holds: the token list
+			const uint32_t t0 = tok_off[subject], nt = tok_off[subject + 1] - t0;
+			for (uint32_t a = 0; a + 1 < nt; a += 2) {
+				const int rk = tok_rank[tok[t0 + a]];
+				if (rk >= 0 && !(seen >> (rk + 1) & 1u)) {
+					dst[rk] = tok[t0 + a + 1];
+					seen |= 1u << (rk + 1);
+				}
+			}
+		}
+	};
+	lineage_of(cnt[r] ? hits[off[r]].subject : -1, nm[0]);
+	lineage_of(soap_subj[r], nm[1]);
+	uint32_t seen_r = 0u;
+	for (uint32_t t = rdp_off[r]; t < rdp_off[r + 1]; t++) {
+		const uint32_t c = rdp_code[t], rk = c & 7u;
+		if (c != 0xFFFFFFFFu && rk >= 1 && !(seen_r >> rk & 1u)) {
+			nm[2][rk - 1] = c >> 3;
+			seen_r |= 1u << rk;
+		}
+	}
+	pgx_vote_rec v;
+	v.depth = rdp_present[r] ? 0 : -1; // -1: the read has no RDP line (no line of text either)
+	for (int k = 0; k < 7; k++) {
+		v.name[k] = 0u;
+		v.votes[k] = 0;
+	}
+	v.pad = 0;
+	if (v.depth == 0) {
+		for (int k = 0; k < 7; k++) {
+			const uint32_t b = nm[0][k], s = nm[1][k], q = nm[2][k];
+			uint32_t w = 0u, votes = 0u;
+			if (b && b == s) {
+				w = b;
+				votes = 2u + (q == b ? 1u : 0u);
+			} else if (b && b == q) {
+				w = b;
+				votes = 2u;
+			} else if (s && s == q) {
+				w = s;
+				votes = 2u;
+			}
+			if (!votes)
+				break;
+			v.name[k] = w;
+			v.votes[k] = (uint8_t)votes;
+			v.depth = k + 1;
+		}
+	}
+	out[r] = v;
+}
+
+extern "C" int pgx_vote3_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_rdp *rdp, const char *soap_path,
+			       pgx_vote_rec *out, int64_t cap)
+{
+	if (!db || !reads || !hits || !rdp || !soap_path || !out)
+		return fail(PGX_E_ARG, "pgx_vote3_batch: null argument");
+	if (!db->bound)
+		return fail(PGX_E_ARG, "pgx_vote3_batch: bind the database to a taxonomy first");
+	if (hits->n_reads != reads->n || rdp->n != reads->n || cap < reads->n)
+		return fail(PGX_E_ARG, "pgx_vote3_batch: the tables cover different read counts");
+	PGX_TRY(require_device());
+	return pgx::guard("pgx_vote3_batch", [&]() -> int {
+		bool ok;
+		const std::string text = read_text_file(soap_path, &ok);
+		if (!ok)
+			return fail(PGX_E_IO, "Error: Unable to open %s file.", soap_path);
+		const size_t n = (size_t)reads->n;
+		// SOAP rows (soap.man: column 1 read name, column 8 reference id): the first row of every read
+		std::vector<int32_t> subj(n ? n : 1, -1);
+		std::unordered_map<std::string, uint32_t> id_of;
+		id_of.reserve((size_t)db->n_seq * 2);
+		for (size_t i = 0; i < (size_t)db->n_seq; i++)
+			id_of.emplace(db->ids[i], (uint32_t)i);
+		const ReadNameIndex index(*reads);
+		for (size_t s0 = 0; s0 < text.size();) {
+			const char *nl = (const char *)memchr(text.data() + s0, '\n', text.size() - s0);
+			const size_t e = nl ? (size_t)(nl - text.data()) : text.size();
+			const char *line = text.data() + s0;
+			const size_t len = e - s0;
+			s0 = e + 1;
+			const char *tab = (const char *)memchr(line, '\t', len);
+			if (!tab)
+				continue;
+			const size_t r = index.find(line, (size_t)(tab - line), 0);
+			if (r >= n || subj[r] != -1)
+				continue;
+			const char *p = tab + 1;
+			for (int col = 1; col < 7 && p; col++) {
+				const char *t2 = (const char *)memchr(p, '\t', (size_t)(line + len - p));
+				p = t2 ? t2 + 1 : nullptr;
+			}
+			if (!p)
+				continue;
+			const char *t2 = (const char *)memchr(p, '\t', (size_t)(line + len - p));
+			auto it = id_of.find(std::string(p, t2 ? (size_t)(t2 - p) : (size_t)(line + len - p)));
+			subj[r] = it == id_of.end() ? -2 : (int32_t)it->second; // -2: a reference the database does not hold (no vote)
+		}
+		for (auto &x : subj)
+			if (x == -2)
+				x = -1;
+		DevBuf<int32_t> d_subj;
+		DevBuf<pgx_vote_rec> d_out;
+		PGX_TRY(d_subj.alloc(n ? n : 1));
+		PGX_TRY(d_subj.upload(subj.data(), n));
+		PGX_TRY(d_out.alloc(n ? n : 1));
+		if (n) {
+			hipLaunchKernelGGL(k_vote3, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, hits->d_hits.data(), hits->d_read_off.data(),
+					   hits->d_read_cnt.data(), d_subj.data(), db->d_subj_pairs.data(), db->d_subj_tok_off.data(),
+					   db->d_subj_tok.data(), db->d_tok_rank.data(), rdp->d_off.data(), rdp->d_code.data(), rdp->d_present.data(),
+					   (uint32_t)n, d_out.data());
+			PGX_HIP(hipGetLastError());
+			PGX_TRY(d_out.download(out, n));
+		}
+		return 0;
+	});
+}
+
+extern "C" int pgx_vote3_format(const pgx_db *db, const pgx_reads *reads, const pgx_vote_rec *recs, int64_t n, char **text, size_t *len)
+{
+	if (!db || !reads || !recs || !text)
+		return fail(PGX_E_ARG, "pgx_vote3_format: null argument");
+	return pgx::guard("pgx_vote3_format", [&]() -> int {
+		Text out;
+		for (int64_t r = 0; r < n && r < reads->n; r++) {
+			const pgx_vote_rec &v = recs[r];
+			if (v.depth < 0)
+				continue;
+			out.s += reads->name_of(r);
+			out.s += '\t';
+			std::string votes;
+			for (int k = 0; k < v.depth && k < 7; k++) {
+				out.printf("[%d]", k);
+				out.s += v.name[k] < db->token_text.size() ? db->token_text[v.name[k]] : std::string();
+				out.s += ';';
+				votes += (char)('0' + v.votes[k]);
+			}
+			out.printf("\t%d\t%s\n", v.depth, votes.c_str());
+		}
+		*text = out.release_malloc(len);
+		return *text ? 0 : fail(PGX_E_NOMEM, "out of memory");
+	});
+}
+
 static void synth_level_counts(const pgx_synth_cfg *c, int64_t cnt[7], int64_t base[7])
 {
 	auto max1 = [](int64_t v) { return v < 1 ? (int64_t)1 : v; };

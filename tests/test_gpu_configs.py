@@ -148,3 +148,48 @@ def test_config5_third_stream_is_opened_and_ignored(pg, oracle_bin, tmp_path):
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c3.txt"), s=str(tmp_path / "soap.txt"))
     assert (tmp_path / "c2.txt").read_bytes() == (tmp_path / "c3.txt").read_bytes() == _capi.consensus_format(db, reads, h2, r2)
+
+
+def test_config5_opt_in_three_way_vote(pg, oracle_bin, tmp_path):
+    """The opt-in extension of SURVEY 8(f) row 4 (spec pgx-vote3 v1; NOT reference behaviour): the SOAP table takes part.
+    Checker: `pgx_oracle vote3` over the taxcollector'd BLAST table, the RDP stream and the taxcollector'd SOAP table
+    (the SOAP rows rewritten as a 12-column table so that taxcollector gives them lineages)."""
+    from pangea_plus_amd import _capi
+    shape = dict(n_seq=3000, seq_len=500, n_genus=60, read_len=150)
+    args = ["--n-seq", "3000", "--seq-len", "500", "--n-genus", "60", "--read-len", "150"]
+    n = 3000
+    (tmp_path / "Tax_class").mkdir()
+    for what, path, extra in (("db", "db.fa", []), ("reads", "reads.fa", ["--count", str(n)]), ("rdp", "rdp.tsv", ["--count", str(n)]),
+                              ("taxdump", "Tax_class", [])):
+        assert run_cmd([oracle_bin, "synth", what, "--out", str(tmp_path / path)] + extra + args)[0] == 0
+    pg.TaxDb.create(str(tmp_path / "Tax_class"))
+    pg.soap_index(str(tmp_path / "db.fa"))
+    pg.soap(str(tmp_path / "reads.fa"), str(tmp_path / "db.fa.index"), str(tmp_path / "soap.txt"), M=4, r=2)
+    # drop the SOAP rows of every 7th read: those reads vote with two streams only
+    rows = [l for l in open(tmp_path / "soap.txt") if int(hashlib.md5(l.split("\t")[0].encode()).hexdigest(), 16) % 7]
+    open(tmp_path / "soap.txt", "w").writelines(rows)
+    with open(tmp_path / "soap12.tsv", "w") as f:
+        for l in rows:
+            c = l.rstrip("\n").split("\t")
+            f.write("\t".join([c[0], c[7], "100.00", c[5], "0", "0", "1", c[5], c[8], c[8], "0.0", "100"]) + "\n")
+    cfg = pg.SynthCfg.default(**shape)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(tmp_path / "Tax_class")))
+    reads = pg.Reads.from_synth(cfg, 0, n)
+    rdp = pg.Rdp.from_synth(cfg, 0, n, db)
+    hits, _ = _capi.classify_consensus(db, reads, rdp)
+    recs, text = _capi.vote3(db, reads, hits, rdp, str(tmp_path / "soap.txt"))
+    # the checker's chain, all on the CPU
+    assert run_cmd([oracle_bin, "blastn", "-query", str(tmp_path / "reads.fa"), "-db", str(tmp_path / "db.fa"), "-outfmt", "6", "-out",
+                    str(tmp_path / "o_hits.tsv"), "-num_threads", "8"], timeout=600)[0] == 0
+    for a, b in (("o_hits.tsv", "o_hits_class.tsv"), ("soap12.tsv", "o_soap_class.tsv")):
+        assert run_cmd([oracle_bin, "taxcollector", "-f", str(tmp_path / a), "-o", str(tmp_path / b), "-d", str(tmp_path / "Tax_class")])[0] == 0
+    assert run_cmd([oracle_bin, "vote3", str(tmp_path / "o_hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "o_soap_class.tsv"),
+                    str(tmp_path / "o_vote.txt")])[0] == 0
+    want = (tmp_path / "o_vote.txt").read_bytes()
+    assert text == want
+    d = recs["depth"]
+    assert (d >= 0).all() and (d >= 5).mean() > 0.5 and (recs["votes"] == 3).any() and (recs["votes"] == 2).any()
+    with pytest.raises(_capi.PangeaError) as e:
+        _capi.vote3(db, reads, hits, rdp, str(tmp_path / "missing.txt"))
+    assert e.value.status == -2
