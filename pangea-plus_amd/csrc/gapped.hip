@@ -30,9 +30,24 @@ constexpr int kGLag = 19;     // floor((X + 1/2) / 3) + 1: the X-drop test looks
 constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel: below kGLag, so it never makes an X-drop test
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
+constexpr int kGGroup = 4;    // diagonals per group of the unrolled row (lane kernel)
 constexpr uint32_t kCellNone = 0x00008000u; // lane kernel: a dead cell holds i = -32768
 constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
 static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
+
+#ifdef PGX_STAGE_PROBES
+// measurement builds: [0] cell steps of a wavefront, [1] cells evaluated by lanes, [2] slide rounds (wavefront) inside cell
+// steps, [3] levels, [4] rounds (sides x 64), [5] lanes with a side, [6] walk rounds of B0, [7] lane-cells alive at level start
+__device__ unsigned long long g_gap_stats[8];
+#define GAP_STAT(i, n)                                          \
+	do {                                                    \
+		const unsigned long long n_ = (unsigned long long)(n); /* (ballots are taken by the whole wavefront) */ \
+		if ((threadIdx.x & 63) == 0)                    \
+			atomicAdd(&g_gap_stats[i], n_);         \
+	} while (0)
+#else
+#define GAP_STAT(i, n) ((void)0)
+#endif
 
 __device__ __forceinline__ void lds_sync()
 {
@@ -101,17 +116,18 @@ __device__ __forceinline__ uint32_t lds_window16(const uint32_t *w, int pos)
 	return (uint32_t)(v >> ((pos & 15) * 2));
 }
 
-// up to 16 letters from read position qp / window position dp on, in direction dir: how many match (0 .. take)
-__device__ __forceinline__ int lcp_chunk(const uint32_t *rd, const uint32_t *db, int dir, int qp, int dp, int take)
+// Letters that match from read position qp / window position dp on in direction dir, at most min(16, cap).  Ascending: the
+// 16-letter window STARTS at the position; descending: it ENDS there (so the word before each staged sequence must be
+// readable: the read row carries one word of padding, the database window starts 16 bases early).  Letters past `cap` are
+// whatever the window holds: the unsigned minimum drops them, and turns "no mismatch" (-1 from the bit scan) into the cap.
+__device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int dir, int qp, int dp, int cap)
 {
-	const int back = dir > 0 ? 0 : take - 1;
+	const int back = dir > 0 ? 0 : 15;
 	const uint32_t x = lds_window16(rd, qp - back) ^ lds_window16(db, dp - back);
-	uint32_t y = (x | (x >> 1)) & 0x55555555u;
-	if (take < 16)
-		y &= (1u << (2 * take)) - 1u;
-	const uint32_t yb = y << (2 * (16 - take));
-	const int fwd = y ? (__ffs((int)y) - 1) >> 1 : take, bwd = yb ? __clz((int)yb) >> 1 : take;
-	return dir > 0 ? fwd : bwd;
+	const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+	const uint32_t f = dir > 0 ? (uint32_t)(__ffs((int)y) - 1) >> 1 : (uint32_t)__clz((int)y) >> 1; // clz(0) = 32
+	const uint32_t r = f < 16u ? f : 16u;
+	return (int)(r < (uint32_t)cap ? r : (uint32_t)cap);
 }
 
 struct GapView {
@@ -177,8 +193,8 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // lives in REGISTERS (kGFastCells words, indexed by the unrolled k) and is updated in place, k ascending.  Lanes whose
 // cell is dead, or that have finished, idle for that step; the caller groups sides of similar cost to keep that rare.
 // cell: bits 0-15 i (signed; kCellNone holds -32768 there, so a dead parent loses every max), 16-20 mismatches, 21-25 gap
-// openings, 26-27 kind of the last difference (0 mismatch, 1 gap in the subject row, 2 gap in the query row), 28: letters
-// matched after it.
+// openings, 26-27 the OPEN gap: the kind of the path's last column (1 gap in the subject row, 2 gap in the query row) if
+// that column is a gap and no letter matched after it, else 0 -- a gap column opens a gap unless it continues that one.
 //
 // A second cut, also unable to change the result while no X-drop test is made (d < kGLag: every score then passes it):
 // B0 = the best score of the path that never leaves the anchor's diagonal, found first with a walk over its mismatches.
@@ -191,13 +207,17 @@ __device__ __forceinline__ int sext16(uint32_t c) { return (int)(int16_t)(uint16
 __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int dir, int q0, int d0, int M, int N,
 					     Side &out)
 {
+	int slide_rounds = 0;
+	(void)slide_rounds;
 	auto slide = [&](int &ii, int &jj) {
 		for (;;) {
+#ifdef PGX_STAGE_PROBES
+			slide_rounds++;
+#endif
 			const int cap = M - ii < N - jj ? M - ii : N - jj;
-			const int take = cap < 16 ? cap : 16;
-			if (take <= 0)
+			if (cap <= 0)
 				break;
-			const int run = lcp_chunk(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, take);
+			const int run = lcp16(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, cap);
 			ii += run;
 			jj += run;
 			if (run < 16)
@@ -206,6 +226,8 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	};
 	out.i = out.j = out.s2 = out.mism = out.gopen = 0;
 	int i0 = 0, j0 = 0;
+	GAP_STAT(4, 1);
+	GAP_STAT(5, __popcll(__ballot(on)));
 	if (on)
 		slide(i0, j0);
 	out.i = out.j = i0;
@@ -217,6 +239,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		int wi = i0, wd = 0;
 		bool walking = live;
 		while (__ballot(walking) != 0ull) {
+			GAP_STAT(6, 1);
 			if (walking) {
 				wd++;
 				wi++;
@@ -238,8 +261,9 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	for (int c = 0; c < kGFastCells; c++)
 		R[c] = kCellNone;
 	constexpr int C = kGFastD + 1;
-	R[C] = live ? (((uint32_t)i0 & 0xFFFFu) | (i0 > 0 ? 1u << 28 : 0u)) : kCellNone;
-	int best = 2 * i0;
+	R[C] = live ? ((uint32_t)i0 & 0xFFFFu) : kCellNone;
+	int best = 2 * i0, best_k = 0;
+	uint32_t best_cell = (uint32_t)i0 & 0xFFFFu; // the cell that holds the best score (its statistics travel in it)
 	const int A2 = 2 * M, B2 = 2 * N;
 	int Lw = 0, Uw = 0; // wave-wide range of diagonals that hold a live cell
 	bool over = false;
@@ -250,10 +274,18 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		}
 		uint32_t prev = kCellNone; // the old value of the cell left of the one being written
 		bool any = false;
+		GAP_STAT(3, 1);
+		GAP_STAT(7, __popcll(__ballot(live)));
 		int nl = 1 << 20, nu = -(1 << 20);
 		const int six_d = 6 * d;
+		// (the unrolled diagonals are tested for "no lane has a parent here" in groups of kGGroup first: a level touches
+		// 2 d + 3 of the 37, and the scalar tests of the others were a seventh of the kernel's instructions)
 #pragma unroll
-		for (int c = 1; c < kGFastCells - 1; c++) {
+		for (int c0 = 1; c0 < kGFastCells - 1; c0 += kGGroup) {
+			if (c0 + kGGroup - 1 - C < Lw - 1 || c0 - C > Uw + 1)
+				continue;
+#pragma unroll
+		for (int c = c0; c < c0 + kGGroup && c < kGFastCells - 1; c++) {
 			const int k = c - C;
 			if (k < Lw - 1 || k > Uw + 1) // wave-uniform: no lane has a parent for this diagonal
 				continue;
@@ -263,29 +295,48 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			const int v = max(vc, max(vp, vn));
 			const bool from_c = (vc >= vp) & (vc >= vn), from_p = !from_c & (vp >= vn);
 			const uint32_t p = from_c ? cur : (from_p ? prev : nxt);
-			const uint32_t par = from_c ? 0u : (from_p ? 1u : 2u);
+			const uint32_t park = from_c ? 0u : (from_p ? 1u << 26 : 2u << 26); // kind of this column, in place
 			const int jj0 = v - k;
 			const int ub = min(A2 - k, B2 + k) - six_d;
-			const bool alive = live & (v >= 0) & (v <= M) & (jj0 <= N) & (jj0 >= 0) & (ub > best) & (ub >= b0);
+			const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (ub > best) & (ub >= b0);
 			uint32_t nc = kCellNone;
+			GAP_STAT(0, 1);
+			GAP_STAT(1, __popcll(__ballot(alive)));
+#ifdef PGX_STAGE_PROBES
+			slide_rounds = 0;
+#endif
 			if (alive) {
+				// the first 16 letters without the loop's bookkeeping: off the anchor's diagonal a run rarely goes further
 				int ii = v, jj = jj0;
-				slide(ii, jj);
-				const uint32_t pk = (p >> 26) & 3u, pslid = (p >> 28) & 1u;
-				const uint32_t mism = ((p >> 16) & 31u) + (par == 0u ? 1u : 0u);
-				const uint32_t gopen = ((p >> 21) & 31u) + (((par != 0u) & !((pk == par) & (pslid == 0u))) ? 1u : 0u);
-				nc = ((uint32_t)ii & 0xFFFFu) | (mism << 16) | (gopen << 21) | (par << 26) | (ii > v ? 1u << 28 : 0u);
+				{
+					const int cap = M - ii < N - jj ? M - ii : N - jj; // >= 0 for a live cell
+					const int run = lcp16(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, cap);
+					ii += run;
+					jj += run;
+					if (run == 16)
+						slide(ii, jj);
+				}
+				// one more mismatch, or one more gap opening unless the column continues the parent's open gap
+				const uint32_t inc = from_c ? 1u << 16 : ((p & (3u << 26)) != park ? 1u << 21 : 0u);
+				nc = ((uint32_t)ii & 0xFFFFu) | ((p & 0x03FF0000u) + inc) | (ii > v ? 0u : park);
 				const int s2 = ii + jj - six_d;
 				if (s2 > best) {
 					best = s2;
-					out.i = ii;
-					out.j = jj;
-					out.s2 = s2;
-					out.mism = (int)mism;
-					out.gopen = (int)gopen;
+					best_cell = nc;
+					best_k = k;
 				}
 				any = true;
 			}
+#ifdef PGX_STAGE_PROBES
+			{
+				int mx = alive ? slide_rounds : 0;
+				for (int sh = 1; sh < 64; sh <<= 1) {
+					const int o = __shfl_xor(mx, sh);
+					mx = o > mx ? o : mx;
+				}
+				GAP_STAT(2, mx);
+			}
+#endif
 			if (__ballot(alive) != 0ull) {
 				nl = k < nl ? k : nl;
 				nu = k;
@@ -293,10 +344,16 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			prev = cur;
 			R[c] = nc;
 		}
+		}
 		live = live && any;
 		Lw = __builtin_amdgcn_readfirstlane(nl);
 		Uw = __builtin_amdgcn_readfirstlane(nu);
 	}
+	out.i = sext16(best_cell);
+	out.j = out.i - best_k;
+	out.s2 = best;
+	out.mism = (int)((best_cell >> 16) & 31u);
+	out.gopen = (int)((best_cell >> 21) & 31u);
 	return !over;
 }
 
@@ -306,7 +363,7 @@ constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of th
 template <int MAXL> struct FastLds {
 	static constexpr int kRd = MAXL / 16 + 2;                          // read strand, 16 bases per word
 	static constexpr int kDb = (MAXL + 2 * kGFastD + 48 + 15) / 16 + 1; // database window
-	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
+	static constexpr int kSeq = (1 + kRd + kDb) | 1; // one word of padding (lcp16), odd stride: lanes that use the same index hit different banks
 	uint32_t seq[64][kSeq];
 	uint32_t bucket[kKeyBuckets];
 	uint16_t order[kBlkItems];
@@ -328,7 +385,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 	using Lds = FastLds<MAXL>;
 	__shared__ Lds lds;
 	const int lane = threadIdx.x & 63;
-	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
+	uint32_t *rdw = lds.seq[lane] + 1, *dbwin = rdw + Lds::kRd;
 	const unsigned long long n_flat = FLAT ? (*flat_count < table_cap ? *flat_count : table_cap) : 0ull;
 	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
 
@@ -508,6 +565,20 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 		}
 	}
 }
+
+#ifdef PGX_STAGE_PROBES
+} // namespace pgx
+extern "C" int pgx_gap_stats(unsigned long long *out, int reset) // measurement builds only (tools/probe_gapstats.py)
+{
+	unsigned long long z[8] = { 0 };
+	if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgx::g_gap_stats), sizeof z) != hipSuccess)
+		return -1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pgx::g_gap_stats), z, sizeof z) != hipSuccess)
+		return -1;
+	return 0;
+}
+namespace pgx {
+#endif
 
 // ------------------------------------------------------------------------------------------ one wavefront per HSP
 // cell: x = i, y = mismatches | gap openings << 12 | kind << 24 | matched-after << 26
