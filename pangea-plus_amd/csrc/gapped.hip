@@ -116,16 +116,37 @@ __device__ __forceinline__ uint32_t lds_window16(const uint32_t *w, int pos)
 	return (uint32_t)(v >> ((pos & 15) * 2));
 }
 
+// the hardware's bit scans as they are: -1 when no bit is set (the C forms add a select for that case)
+__device__ __forceinline__ uint32_t scan_low(uint32_t y)
+{
+	uint32_t f;
+	asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(y));
+	return f;
+}
+__device__ __forceinline__ uint32_t scan_high(uint32_t y)
+{
+	uint32_t f;
+	asm("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(y));
+	return f;
+}
+
 // Letters that match from read position qp / window position dp on in direction dir, at most min(16, cap).  Ascending: the
 // 16-letter window STARTS at the position; descending: it ENDS there (so the word before each staged sequence must be
 // readable: the read row carries one word of padding, the database window starts 16 bases early).  Letters past `cap` are
 // whatever the window holds: the unsigned minimum drops them, and turns "no mismatch" (-1 from the bit scan) into the cap.
-__device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int dir, int qp, int dp, int cap)
+// (positions arrive as BIT offsets, 2 per letter, already moved back by 15 letters for the descending direction: the
+// funnel shift takes its amount from the low five bits as they are)
+__device__ __forceinline__ uint32_t lds_window16_bits(const uint32_t *w, int bit)
 {
-	const int back = dir > 0 ? 0 : 15;
-	const uint32_t x = lds_window16(rd, qp - back) ^ lds_window16(db, dp - back);
+	const int i = bit >> 5;
+	return __builtin_amdgcn_alignbit(w[i + 1], w[i], (uint32_t)bit);
+}
+
+__device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int dir, int qbit, int dbit, int cap)
+{
+	const uint32_t x = lds_window16_bits(rd, qbit) ^ lds_window16_bits(db, dbit);
 	const uint32_t y = (x | (x >> 1)) & 0x55555555u;
-	const uint32_t f = dir > 0 ? (uint32_t)(__ffs((int)y) - 1) >> 1 : (uint32_t)__clz((int)y) >> 1; // clz(0) = 32
+	const uint32_t f = (dir > 0 ? scan_low(y) : scan_high(y)) >> 1;
 	const uint32_t r = f < 16u ? f : 16u;
 	return (int)(r < (uint32_t)cap ? r : (uint32_t)cap);
 }
@@ -209,6 +230,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 {
 	int slide_rounds = 0;
 	(void)slide_rounds;
+	const int q0b = 2 * (q0 - (dir > 0 ? 0 : 15)), d0b = 2 * (d0 - (dir > 0 ? 0 : 15)); // bit offsets of the side's first window
 	auto slide = [&](int &ii, int &jj) {
 		for (;;) {
 #ifdef PGX_STAGE_PROBES
@@ -217,7 +239,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			const int cap = M - ii < N - jj ? M - ii : N - jj;
 			if (cap <= 0)
 				break;
-			const int run = lcp16(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, cap);
+			const int run = lcp16(rdw, dbwin, dir, q0b + 2 * dir * ii, d0b + 2 * dir * jj, cap);
 			ii += run;
 			jj += run;
 			if (run < 16)
@@ -265,7 +287,6 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	int best = 2 * i0, best_k = 0;
 	uint32_t best_cell = (uint32_t)i0 & 0xFFFFu; // the cell that holds the best score (its statistics travel in it)
 	const int A2 = 2 * M, B2 = 2 * N;
-	int Lw = 0, Uw = 0; // wave-wide range of diagonals that hold a live cell
 	bool over = false;
 	for (int d = 1; __ballot(live) != 0ull; d++) {
 		if (d > kGFastD) {
@@ -276,19 +297,18 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		bool any = false;
 		GAP_STAT(3, 1);
 		GAP_STAT(7, __popcll(__ballot(live)));
-		int nl = 1 << 20, nu = -(1 << 20);
 		const int six_d = 6 * d;
 		// (the unrolled diagonals are tested for "no lane has a parent here" in groups of kGGroup first: a level touches
 		// 2 d + 3 of the 37, and the scalar tests of the others were a seventh of the kernel's instructions)
 #pragma unroll
 		for (int c0 = 1; c0 < kGFastCells - 1; c0 += kGGroup) {
-			if (c0 + kGGroup - 1 - C < Lw - 1 || c0 - C > Uw + 1)
+				if (c0 + kGGroup - 1 - C < -d || c0 - C > d)
 				continue;
 #pragma unroll
 		for (int c = c0; c < c0 + kGGroup && c < kGFastCells - 1; c++) {
 			const int k = c - C;
-			if (k < Lw - 1 || k > Uw + 1) // wave-uniform: no lane has a parent for this diagonal
-				continue;
+			if (k < -d || k > d) // level d reaches the diagonals -d .. d (following the range that still holds live cells
+				continue;    // saved 2 of 54 cell steps per side and cost 6 instructions in each of them)
 			const uint32_t cur = R[c], nxt = R[c + 1];
 			// the three parents without a branch: a mismatch on this diagonal wins ties, then diagonal k - 1, then k + 1
 			const int vc = sext16(cur) + 1, vp = sext16(prev) + 1, vn = sext16(nxt);
@@ -310,7 +330,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				int ii = v, jj = jj0;
 				{
 					const int cap = M - ii < N - jj ? M - ii : N - jj; // >= 0 for a live cell
-					const int run = lcp16(rdw, dbwin, dir, q0 + dir * ii, d0 + dir * jj, cap);
+					const int run = lcp16(rdw, dbwin, dir, q0b + 2 * dir * ii, d0b + 2 * dir * jj, cap);
 					ii += run;
 					jj += run;
 					if (run == 16)
@@ -337,17 +357,11 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				GAP_STAT(2, mx);
 			}
 #endif
-			if (__ballot(alive) != 0ull) {
-				nl = k < nl ? k : nl;
-				nu = k;
-			}
 			prev = cur;
 			R[c] = nc;
 		}
 		}
 		live = live && any;
-		Lw = __builtin_amdgcn_readfirstlane(nl);
-		Uw = __builtin_amdgcn_readfirstlane(nu);
 	}
 	out.i = sext16(best_cell);
 	out.j = out.i - best_k;
