@@ -31,7 +31,7 @@ constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
 constexpr int kGGroup = 4;    // diagonals per group of the unrolled row (lane kernel)
-constexpr uint32_t kCellNone = 0x00008000u; // lane kernel: a dead cell holds i = -32768
+constexpr uint32_t kCellNone = 0x80000000u; // lane kernel: a dead cell holds i = -32768
 constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
 static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
 
@@ -213,9 +213,12 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // One side of a lane's HSP, all 64 lanes in step: the loops over d and k are wave-uniform, so the row R(d, .) of a lane
 // lives in REGISTERS (kGFastCells words, indexed by the unrolled k) and is updated in place, k ascending.  Lanes whose
 // cell is dead, or that have finished, idle for that step; the caller groups sides of similar cost to keep that rare.
-// cell: bits 0-15 i (signed; kCellNone holds -32768 there, so a dead parent loses every max), 16-20 mismatches, 21-25 gap
-// openings, 26-27 the OPEN gap: the kind of the path's last column (1 gap in the subject row, 2 gap in the query row) if
-// that column is a gap and no letter matched after it, else 0 -- a gap column opens a gap unless it continues that one.
+// cell: bits 16-31 i (signed; kCellNone holds -32768 there, so a dead parent loses every maximum), 14-15 zero (the
+// parents' priority goes there while they are compared), 7-11 mismatches, 2-6 gap openings, 0-1 the OPEN gap: the kind of
+// the path's last column (1 gap in the subject row, 2 gap in the query row) if that column is a gap and no letter matched
+// after it, else 0 -- a gap column opens a gap unless it continues that one.  With i on top, ONE signed maximum over the
+// three parent words (each moved to the row it would reach, its priority in bits 14-15) yields the furthest row, the
+// parent that wins ties (this diagonal, then k - 1, then k + 1) and that parent's statistics together.
 //
 // A second cut, also unable to change the result while no X-drop test is made (d < kGLag: every score then passes it):
 // B0 = the best score of the path that never leaves the anchor's diagonal, found first with a walk over its mismatches.
@@ -283,10 +286,13 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	for (int c = 0; c < kGFastCells; c++)
 		R[c] = kCellNone;
 	constexpr int C = kGFastD + 1;
-	R[C] = live ? ((uint32_t)i0 & 0xFFFFu) : kCellNone;
-	int best = 2 * i0, best_k = 0;
-	uint32_t best_cell = (uint32_t)i0 & 0xFFFFu; // the cell that holds the best score (its statistics travel in it)
+	R[C] = live ? (uint32_t)i0 << 16 : kCellNone;
+	// `best` starts one below B0 when the anchor's diagonal does better than its first run: no cell below B0 can be the
+	// answer (the diagonal's own cells reach B0), so the bound test needs one number, not two
+	int best = 2 * i0 > b0 - 1 ? 2 * i0 : b0 - 1, best_k = 0;
+	uint32_t best_cell = (uint32_t)i0 << 16; // the cell that holds the best score (its statistics travel in it)
 	const int A2 = 2 * M, B2 = 2 * N;
+	int slack_q = A2 - best, slack_s = B2 - best;
 	bool over = false;
 	for (int d = 1; __ballot(live) != 0ull; d++) {
 		if (d > kGFastD) {
@@ -310,15 +316,12 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			if (k < -d || k > d) // level d reaches the diagonals -d .. d (following the range that still holds live cells
 				continue;    // saved 2 of 54 cell steps per side and cost 6 instructions in each of them)
 			const uint32_t cur = R[c], nxt = R[c + 1];
-			// the three parents without a branch: a mismatch on this diagonal wins ties, then diagonal k - 1, then k + 1
-			const int vc = sext16(cur) + 1, vp = sext16(prev) + 1, vn = sext16(nxt);
-			const int v = max(vc, max(vp, vn));
-			const bool from_c = (vc >= vp) & (vc >= vn), from_p = !from_c & (vp >= vn);
-			const uint32_t p = from_c ? cur : (from_p ? prev : nxt);
-			const uint32_t park = from_c ? 0u : (from_p ? 1u << 26 : 2u << 26); // kind of this column, in place
+			const int m3 = max((int)(cur + 0x00018000u), max((int)(prev + 0x00014000u), (int)nxt));
+			const int v = m3 >> 16;
+			const uint32_t kind = 2u - (((uint32_t)m3 >> 14) & 3u); // 0: mismatch on this diagonal, 1: from k - 1, 2: from k + 1
 			const int jj0 = v - k;
-			const int ub = min(A2 - k, B2 + k) - six_d;
-			const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (ub > best) & (ub >= b0);
+			// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers
+			const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
 			uint32_t nc = kCellNone;
 			GAP_STAT(0, 1);
 			GAP_STAT(1, __popcll(__ballot(alive)));
@@ -337,14 +340,17 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 						slide(ii, jj);
 				}
 				// one more mismatch, or one more gap opening unless the column continues the parent's open gap
-				const uint32_t inc = from_c ? 1u << 16 : ((p & (3u << 26)) != park ? 1u << 21 : 0u);
-				nc = ((uint32_t)ii & 0xFFFFu) | ((p & 0x03FF0000u) + inc) | (ii > v ? 0u : park);
+				const uint32_t pst = (uint32_t)m3;
+				const uint32_t inc = kind == 0u ? 1u << 7 : ((pst & 3u) != kind ? 1u << 2 : 0u);
+				nc = ((uint32_t)ii << 16) | (((pst & 0xFFCu) + inc) | (ii > v ? 0u : kind));
 				const int s2 = ii + jj - six_d;
 				if (s2 > best) {
 					best = s2;
 					best_cell = nc;
 					best_k = k;
 				}
+				slack_q = A2 - best;
+				slack_s = B2 - best;
 				any = true;
 			}
 #ifdef PGX_STAGE_PROBES
@@ -363,11 +369,11 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		}
 		live = live && any;
 	}
-	out.i = sext16(best_cell);
+	out.i = (int)best_cell >> 16;
 	out.j = out.i - best_k;
-	out.s2 = best;
-	out.mism = (int)((best_cell >> 16) & 31u);
-	out.gopen = (int)((best_cell >> 21) & 31u);
+	out.s2 = best > 2 * i0 ? best : 2 * i0; // (no cell passed the first run: B0 was that run)
+	out.mism = (int)((best_cell >> 7) & 31u);
+	out.gopen = (int)((best_cell >> 2) & 31u);
 	return !over;
 }
 
