@@ -123,30 +123,23 @@ __device__ __forceinline__ uint32_t scan_low(uint32_t y)
 	asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(y));
 	return f;
 }
-__device__ __forceinline__ uint32_t scan_high(uint32_t y)
-{
-	uint32_t f;
-	asm("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(y));
-	return f;
-}
 
-// Letters that match from read position qp / window position dp on in direction dir, at most min(16, cap).  Ascending: the
-// 16-letter window STARTS at the position; descending: it ENDS there (so the word before each staged sequence must be
-// readable: the read row carries one word of padding, the database window starts 16 bases early).  Letters past `cap` are
-// whatever the window holds: the unsigned minimum drops them, and turns "no mismatch" (-1 from the bit scan) into the cap.
-// (positions arrive as BIT offsets, 2 per letter, already moved back by 15 letters for the descending direction: the
-// funnel shift takes its amount from the low five bits as they are)
+// Letters that match from read position qp / window position dp on (positions as BIT offsets, 2 per letter: the funnel
+// shift takes its amount from the low five bits as they are), at most min(16, cap).  Letters past `cap` are whatever the
+// window holds: the unsigned minimum drops them, and turns "no mismatch" (-1 from the bit scan) into the cap.
+// Only ascending: the side LEFT of the anchor is staged reversed (see k_gapped_fast), so one copy of the row code serves
+// both sides -- half the instruction footprint of the kernel.
 __device__ __forceinline__ uint32_t lds_window16_bits(const uint32_t *w, int bit)
 {
 	const int i = bit >> 5;
 	return __builtin_amdgcn_alignbit(w[i + 1], w[i], (uint32_t)bit);
 }
 
-__device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int dir, int qbit, int dbit, int cap)
+__device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int qbit, int dbit, int cap)
 {
 	const uint32_t x = lds_window16_bits(rd, qbit) ^ lds_window16_bits(db, dbit);
 	const uint32_t y = (x | (x >> 1)) & 0x55555555u;
-	const uint32_t f = (dir > 0 ? scan_low(y) : scan_high(y)) >> 1;
+	const uint32_t f = scan_low(y) >> 1;
 	const uint32_t r = f < 16u ? f : 16u;
 	return (int)(r < (uint32_t)cap ? r : (uint32_t)cap);
 }
@@ -228,12 +221,11 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // Returns false for a lane whose cells are still alive after kGFastD differences.
 __device__ __forceinline__ int sext16(uint32_t c) { return (int)(int16_t)(uint16_t)c; }
 
-__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int dir, int q0, int d0, int M, int N,
-					     Side &out)
+__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int q0, int d0, int M, int N, Side &out)
 {
 	int slide_rounds = 0;
 	(void)slide_rounds;
-	const int q0b = 2 * (q0 - (dir > 0 ? 0 : 15)), d0b = 2 * (d0 - (dir > 0 ? 0 : 15)); // bit offsets of the side's first window
+	const int q0b = 2 * q0, d0b = 2 * d0; // bit offsets of the side's first letters
 	auto slide = [&](int &ii, int &jj) {
 		for (;;) {
 #ifdef PGX_STAGE_PROBES
@@ -242,7 +234,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			const int cap = M - ii < N - jj ? M - ii : N - jj;
 			if (cap <= 0)
 				break;
-			const int run = lcp16(rdw, dbwin, dir, q0b + 2 * dir * ii, d0b + 2 * dir * jj, cap);
+			const int run = lcp16(rdw, dbwin, q0b + 2 * ii, d0b + 2 * jj, cap);
 			ii += run;
 			jj += run;
 			if (run < 16)
@@ -333,7 +325,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				int ii = v, jj = jj0;
 				{
 					const int cap = M - ii < N - jj ? M - ii : N - jj; // >= 0 for a live cell
-					const int run = lcp16(rdw, dbwin, dir, q0b + 2 * dir * ii, d0b + 2 * dir * jj, cap);
+					const int run = lcp16(rdw, dbwin, q0b + 2 * ii, d0b + 2 * jj, cap);
 					ii += run;
 					jj += run;
 					if (run == 16)
@@ -383,7 +375,7 @@ constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of th
 template <int MAXL> struct FastLds {
 	static constexpr int kRd = MAXL / 16 + 2;                          // read strand, 16 bases per word
 	static constexpr int kDb = (MAXL + 2 * kGFastD + 48 + 15) / 16 + 1; // database window
-	static constexpr int kSeq = (1 + kRd + kDb) | 1; // one word of padding (lcp16), odd stride: lanes that use the same index hit different banks
+	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
 	uint32_t seq[64][kSeq];
 	uint32_t bucket[kKeyBuckets];
 	uint16_t order[kBlkItems];
@@ -405,7 +397,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 	using Lds = FastLds<MAXL>;
 	__shared__ Lds lds;
 	const int lane = threadIdx.x & 63;
-	uint32_t *rdw = lds.seq[lane] + 1, *dbwin = rdw + Lds::kRd;
+	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
 	const unsigned long long n_flat = FLAT ? (*flat_count < table_cap ? *flat_count : table_cap) : 0ull;
 	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
 
@@ -502,7 +494,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 					a.gpos = 0;
 					a.s.rw = a.s.ra = a.s.dbw = a.s.dba = nullptr;
 					bool on = false;
-					int awin = 0; // the anchor's position in the staged window
+					int awin = 0, sq0 = 0, sd0 = 0; // the anchor's position in the window; where the side starts in the staged rows
 					uint2 parked = make_uint2(0u, 0u);
 					if (mine) {
 						h = *hp;
@@ -532,17 +524,31 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 							}
 						}
 						if (!wide) {
-							// this side's letters: read [0, qa) and the window left of the anchor, or the rest
 							const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw);
-							const int r0 = side ? a.qa >> 4 : 0, r1 = side ? Lds::kRd : (a.qa >> 4) + 2;
-							for (int w = r0; w < r1 && w < Lds::kRd; w++)
-								rdw[w] = gr[w];
 							const uint32_t *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
-							const int mid = (int)(((int64_t)a.gpos >> 4) - lo); // window word that holds the anchor
-							const int d0w = side ? mid : 0, d1w = side ? Lds::kDb : mid + 2;
-							for (int w = d0w; w < d1w && w < Lds::kDb; w++)
-								dbwin[w] = gd[w];
-							awin = (int)((int64_t)a.gpos - lo * 16);
+							awin = (int)((int64_t)a.gpos - lo * 16); // the anchor's position in the window (>= qa + 34)
+							if (side) {
+								// right of the anchor: the read from the anchor's word on, the window likewise
+								for (int w = a.qa >> 4; w < Lds::kRd; w++)
+									rdw[w] = gr[w];
+								for (int w = awin >> 4; w < Lds::kDb; w++)
+									dbwin[w] = gd[w];
+								sq0 = a.qa;
+								sd0 = awin;
+							} else {
+								// left of the anchor, REVERSED: whole words in reverse order, each with its bits reversed (the two
+								// bits of a letter swap in both sequences alike, and letters are only ever compared); letter y of W
+								// words lands at 16 W - 1 - y, so the side starts at 16 W - (anchor position)
+								const int wr = (a.qa + 15) >> 4, wd = (awin + 15) >> 4;
+								for (int w = 0; w < wr; w++)
+									rdw[w] = __builtin_bitreverse32(gr[wr - 1 - w]);
+								rdw[wr] = 0u; // (the window of the last letters reads one word further)
+								for (int w = 0; w < wd; w++)
+									dbwin[w] = __builtin_bitreverse32(gd[wd - 1 - w]);
+								dbwin[wd] = 0u;
+								sq0 = 16 * wr - a.qa;
+								sd0 = 16 * wd - awin;
+							}
 							on = true;
 						}
 					}
@@ -555,10 +561,7 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 						lds_sync();
 						continue; // (probe: ordering + staging only)
 					}
-					if (side == 0)
-						ok = greedy_rows(rdw, dbwin, on, -1, a.qa - 1, awin - 1, a.qa, a.sa, sd);
-					else
-						ok = greedy_rows(rdw, dbwin, on, +1, a.qa, awin, a.L - a.qa, a.slen - a.sa, sd);
+					ok = greedy_rows(rdw, dbwin, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, sd);
 					if (mine) {
 						if (side == 0) {
 							// parked: i | j << 10 | mismatches << 20 | gap openings << 25 ; gap columns | wide << 31
