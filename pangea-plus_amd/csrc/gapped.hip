@@ -20,6 +20,7 @@
 // the result (a child's bound is below its parent's, so no surviving cell has a cut parent; a cut cell never holds the
 // best score), which is why the sequential kernel, the parallel one (bound taken one step late) and the checker (no
 // cut at all) agree.
+#include <type_traits>
 #include "bitops.hpp"
 #include "engine.hpp"
 
@@ -31,6 +32,7 @@ constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
 constexpr int kGGroup = 4;    // diagonals per group of the unrolled row (lane kernel)
+constexpr int kGUnrollLevels = 5; // levels of the lane kernel compiled as straight code
 constexpr uint32_t kCellNone = 0x80000000u; // lane kernel: a dead cell holds i = -32768
 constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
 static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
@@ -48,6 +50,15 @@ __device__ unsigned long long g_gap_stats[8];
 #else
 #define GAP_STAT(i, n) ((void)0)
 #endif
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+	if constexpr (B < E) {
+		f(std::integral_constant<int, B>{});
+		static_for<B + 1, E>(f);
+	}
+}
 
 __device__ __forceinline__ void lds_sync()
 {
@@ -286,79 +297,102 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	const int A2 = 2 * M, B2 = 2 * N;
 	int slack_q = A2 - best, slack_s = B2 - best;
 	bool over = false;
-	for (int d = 1; __ballot(live) != 0ull; d++) {
+	uint32_t prev = kCellNone; // the old value of the cell left of the one being written
+	bool any = false;
+	// one cell of level d (six_d = 6 d), c a compile-time index into the row
+	auto cell = [&](auto cc, int six_d) {
+		constexpr int c = decltype(cc)::value;
+		constexpr int k = c - C;
+		const uint32_t cur = R[c], nxt = R[c + 1];
+		const int m3 = max((int)(cur + 0x00018000u), max((int)(prev + 0x00014000u), (int)nxt));
+		const int v = m3 >> 16;
+		const uint32_t kind = 2u - (((uint32_t)m3 >> 14) & 3u); // 0: mismatch on this diagonal, 1: from k - 1, 2: from k + 1
+		const int jj0 = v - k;
+		// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers
+		const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
+		uint32_t nc = kCellNone;
+		GAP_STAT(0, 1);
+		GAP_STAT(1, __popcll(__ballot(alive)));
+#ifdef PGX_STAGE_PROBES
+		slide_rounds = 0;
+#endif
+		if (alive) {
+			// the first 16 letters without the loop's bookkeeping: off the anchor's diagonal a run rarely goes further
+			int ii = v, jj = jj0;
+			{
+				const int cap = M - ii < N - jj ? M - ii : N - jj; // >= 0 for a live cell
+				const int run = lcp16(rdw, dbwin, q0b + 2 * ii, d0b + 2 * jj, cap);
+				ii += run;
+				jj += run;
+				if (run == 16)
+					slide(ii, jj);
+			}
+			// one more mismatch, or one more gap opening unless the column continues the parent's open gap
+			const uint32_t pst = (uint32_t)m3;
+			const uint32_t inc = kind == 0u ? 1u << 7 : ((pst & 3u) != kind ? 1u << 2 : 0u);
+			nc = ((uint32_t)ii << 16) | (((pst & 0xFFCu) + inc) | (ii > v ? 0u : kind));
+			const int s2 = ii + jj - six_d;
+			if (s2 > best) {
+				best = s2;
+				best_cell = nc;
+				best_k = k;
+			}
+			slack_q = A2 - best;
+			slack_s = B2 - best;
+			any = true;
+		}
+#ifdef PGX_STAGE_PROBES
+		{
+			int mx = alive ? slide_rounds : 0;
+			for (int sh = 1; sh < 64; sh <<= 1) {
+				const int o = __shfl_xor(mx, sh);
+				mx = o > mx ? o : mx;
+			}
+			GAP_STAT(2, mx);
+		}
+#endif
+		prev = cur;
+		R[c] = nc;
+	};
+	// The first kGUnrollLevels levels as straight code: level d is the diagonals -d .. d, known when compiling, so they
+	// carry no tests at all (most sides of a 150-base read end within them); the later levels share one unrolled row
+	// whose diagonals are tested, in groups of kGGroup first, for "level d does not reach this one".
+	bool done = false;
+	static_for<1, kGUnrollLevels + 1>([&](auto dc) {
+		constexpr int d = decltype(dc)::value;
+		if (!done) {
+			if (__ballot(live) == 0ull) {
+				done = true;
+			} else {
+				prev = kCellNone;
+				any = false;
+				GAP_STAT(3, 1);
+				GAP_STAT(7, __popcll(__ballot(live)));
+				static_for<C - d, C + d + 1>([&](auto cc) { cell(cc, 6 * d); });
+				live = live && any;
+			}
+		}
+	});
+	for (int d = kGUnrollLevels + 1; !done && __ballot(live) != 0ull; d++) {
 		if (d > kGFastD) {
 			over = live;
 			break;
 		}
-		uint32_t prev = kCellNone; // the old value of the cell left of the one being written
-		bool any = false;
+		prev = kCellNone;
+		any = false;
 		GAP_STAT(3, 1);
 		GAP_STAT(7, __popcll(__ballot(live)));
 		const int six_d = 6 * d;
-		// (the unrolled diagonals are tested for "no lane has a parent here" in groups of kGGroup first: a level touches
-		// 2 d + 3 of the 37, and the scalar tests of the others were a seventh of the kernel's instructions)
-#pragma unroll
-		for (int c0 = 1; c0 < kGFastCells - 1; c0 += kGGroup) {
-				if (c0 + kGGroup - 1 - C < -d || c0 - C > d)
-				continue;
-#pragma unroll
-		for (int c = c0; c < c0 + kGGroup && c < kGFastCells - 1; c++) {
-			const int k = c - C;
-			if (k < -d || k > d) // level d reaches the diagonals -d .. d (following the range that still holds live cells
-				continue;    // saved 2 of 54 cell steps per side and cost 6 instructions in each of them)
-			const uint32_t cur = R[c], nxt = R[c + 1];
-			const int m3 = max((int)(cur + 0x00018000u), max((int)(prev + 0x00014000u), (int)nxt));
-			const int v = m3 >> 16;
-			const uint32_t kind = 2u - (((uint32_t)m3 >> 14) & 3u); // 0: mismatch on this diagonal, 1: from k - 1, 2: from k + 1
-			const int jj0 = v - k;
-			// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers
-			const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
-			uint32_t nc = kCellNone;
-			GAP_STAT(0, 1);
-			GAP_STAT(1, __popcll(__ballot(alive)));
-#ifdef PGX_STAGE_PROBES
-			slide_rounds = 0;
-#endif
-			if (alive) {
-				// the first 16 letters without the loop's bookkeeping: off the anchor's diagonal a run rarely goes further
-				int ii = v, jj = jj0;
-				{
-					const int cap = M - ii < N - jj ? M - ii : N - jj; // >= 0 for a live cell
-					const int run = lcp16(rdw, dbwin, q0b + 2 * ii, d0b + 2 * jj, cap);
-					ii += run;
-					jj += run;
-					if (run == 16)
-						slide(ii, jj);
-				}
-				// one more mismatch, or one more gap opening unless the column continues the parent's open gap
-				const uint32_t pst = (uint32_t)m3;
-				const uint32_t inc = kind == 0u ? 1u << 7 : ((pst & 3u) != kind ? 1u << 2 : 0u);
-				nc = ((uint32_t)ii << 16) | (((pst & 0xFFCu) + inc) | (ii > v ? 0u : kind));
-				const int s2 = ii + jj - six_d;
-				if (s2 > best) {
-					best = s2;
-					best_cell = nc;
-					best_k = k;
-				}
-				slack_q = A2 - best;
-				slack_s = B2 - best;
-				any = true;
+		static_for<0, (kGFastCells - 2 + kGGroup - 1) / kGGroup>([&](auto gc) {
+			constexpr int c0 = 1 + decltype(gc)::value * kGGroup;
+			if (!(c0 + kGGroup - 1 - C < -d || c0 - C > d)) {
+				static_for<c0, (c0 + kGGroup < kGFastCells - 1 ? c0 + kGGroup : kGFastCells - 1)>([&](auto cc) {
+					constexpr int k = decltype(cc)::value - C;
+					if (!(k < -d || k > d))
+						cell(cc, six_d);
+				});
 			}
-#ifdef PGX_STAGE_PROBES
-			{
-				int mx = alive ? slide_rounds : 0;
-				for (int sh = 1; sh < 64; sh <<= 1) {
-					const int o = __shfl_xor(mx, sh);
-					mx = o > mx ? o : mx;
-				}
-				GAP_STAT(2, mx);
-			}
-#endif
-			prev = cur;
-			R[c] = nc;
-		}
-		}
+		});
 		live = live && any;
 	}
 	out.i = (int)best_cell >> 16;
