@@ -32,7 +32,7 @@ constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel
 constexpr int kGDmax = 1000;  // differences per side, spec
 constexpr int kGFastCells = 2 * kGFastD + 3;
 constexpr int kGGroup = 4;    // diagonals per group of the unrolled row (lane kernel)
-constexpr int kGUnrollLevels = 5; // levels of the lane kernel compiled as straight code
+constexpr int kGUnrollLevels = 7; // levels of the lane kernel compiled as straight code
 constexpr uint32_t kCellNone = 0x80000000u; // lane kernel: a dead cell holds i = -32768
 constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
 static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
@@ -300,16 +300,35 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	uint32_t prev = kCellNone; // the old value of the cell left of the one being written
 	bool any = false;
 	// one cell of level d (six_d = 6 d), c a compile-time index into the row
-	auto cell = [&](auto cc, int six_d) {
+	// (`reach` = the widest diagonal the level before could have written, when that is known while compiling: parents
+	// beyond it are dead without looking)
+	auto cell = [&](auto cc, int six_d, auto reach_c) {
 		constexpr int c = decltype(cc)::value;
 		constexpr int k = c - C;
+		constexpr int reach = decltype(reach_c)::value;
 		const uint32_t cur = R[c], nxt = R[c + 1];
-		const int m3 = max((int)(cur + 0x00018000u), max((int)(prev + 0x00014000u), (int)nxt));
+		int m3;
+		if constexpr (k - 1 < -reach && k > reach) // (level 1, k = +1 handled below; this is never true)
+			m3 = (int)kCellNone;
+		else if constexpr (k < -reach)
+			m3 = (int)nxt; // the left edge of the level: only diagonal k + 1 can lead here
+		else if constexpr (k > reach)
+			m3 = (int)(prev + 0x00014000u); // the right edge: only diagonal k - 1
+		else if constexpr (k - 1 < -reach && k + 1 > reach)
+			m3 = (int)(cur + 0x00018000u); // level 1, k = 0
+		else if constexpr (k - 1 < -reach)
+			m3 = max((int)(cur + 0x00018000u), (int)nxt);
+		else if constexpr (k + 1 > reach)
+			m3 = max((int)(cur + 0x00018000u), (int)(prev + 0x00014000u));
+		else
+			m3 = max((int)(cur + 0x00018000u), max((int)(prev + 0x00014000u), (int)nxt));
 		const int v = m3 >> 16;
 		const uint32_t kind = 2u - (((uint32_t)m3 >> 14) & 3u); // 0: mismatch on this diagonal, 1: from k - 1, 2: from k + 1
 		const int jj0 = v - k;
 		// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers
-		const bool alive = live & ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
+		// (a lane that is not live holds a row of dead cells -- every cell of its last level was written dead -- so it
+		// needs no test of its own: v is -32768 there)
+		const bool alive = ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
 		uint32_t nc = kCellNone;
 		GAP_STAT(0, 1);
 		GAP_STAT(1, __popcll(__ballot(alive)));
@@ -368,8 +387,8 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				any = false;
 				GAP_STAT(3, 1);
 				GAP_STAT(7, __popcll(__ballot(live)));
-				static_for<C - d, C + d + 1>([&](auto cc) { cell(cc, 6 * d); });
-				live = live && any;
+				static_for<C - d, C + d + 1>([&](auto cc) { cell(cc, 6 * d, std::integral_constant<int, d - 1>{}); });
+				live = any;
 			}
 		}
 	});
@@ -389,11 +408,11 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				static_for<c0, (c0 + kGGroup < kGFastCells - 1 ? c0 + kGGroup : kGFastCells - 1)>([&](auto cc) {
 					constexpr int k = decltype(cc)::value - C;
 					if (!(k < -d || k > d))
-						cell(cc, six_d);
+						cell(cc, six_d, std::integral_constant<int, kGFastD>{});
 				});
 			}
 		});
-		live = live && any;
+		live = any;
 	}
 	out.i = (int)best_cell >> 16;
 	out.j = out.i - best_k;
