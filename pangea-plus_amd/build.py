@@ -22,6 +22,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 if os.environ.get("PGX_STAGE_PROBES"):  # measurement builds only: kernels that can be truncated after a stage
     FLAGS.append("-DPGX_STAGE_PROBES")
+FLAGS += os.environ.get("PGX_EXTRA_FLAGS", "").split()  # experiments (-D switches of the kernels under study)
 
 
 def hipcc():

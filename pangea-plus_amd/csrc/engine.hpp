@@ -290,6 +290,7 @@ struct GappedWork {
 	DevBuf<unsigned long long> big_list;
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats)
 	DevBuf<uint2> side_main, side_ovf; // per table slot: the left side's extension, parked until the right side is done
+	DevBuf<uint32_t> order;            // per block of k_gapped_fast: the pool's HSPs in cost order
 };
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,

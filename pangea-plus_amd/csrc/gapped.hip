@@ -431,7 +431,9 @@ template <int MAXL> struct FastLds {
 	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
 	uint32_t seq[64][kSeq];
 	uint32_t bucket[kKeyBuckets];
-	uint16_t order[kBlkItems];
+	// (the pool's HSPs in cost order live in GLOBAL scratch, one array per block: with them here the kernel held 12.6 KB of
+	// LDS per wavefront = 3 wavefronts per SIMD; without, 8.5 KB = 4, and a wavefront of this kernel is bound by its own
+	// instruction issue, so the fourth one is worth a fifth of the stage: 74.6 -> 64.8 ms per 10 M reads)
 	// (no copy of the work keys: 2 KB more LDS costs a wavefront per SIMD, and the rows are bound by vector issue:
 	// 12.6 KB -> 14.7 KB per wavefront ran 24 -> 31 ms per 2 M reads; 1 024-HSP chunks fill the buckets too thinly: 31 ms)
 };
@@ -441,14 +443,16 @@ template <int MAXL> struct FastLds {
 // A wavefront takes the HSPs of 64 reads (at most kBlkItems at a time), orders them by the seed stage's work estimate
 // (a counting sort in LDS), and runs them 64 at a time: lanes of one round have about the same number of rows.
 template <bool FLAT, int MAXL>
-__global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
+// (4 wavefronts per SIMD: 128 registers -- the row is 39 of them; the compiler parks three values in scratch around the rows)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
 						     const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
 						     uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
 						     unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
-						     uint2 *__restrict__ side_res, int dbg)
+						     uint2 *__restrict__ side_res, int dbg, uint32_t *__restrict__ order_all)
 {
 	using Lds = FastLds<MAXL>;
 	__shared__ Lds lds;
+	uint32_t *order = order_all + (size_t)blockIdx.x * kBlkItems; // written and read by this wavefront only, through L2
 	const int lane = threadIdx.x & 63;
 	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
 	const unsigned long long n_flat = FLAT ? (*flat_count < table_cap ? *flat_count : table_cap) : 0ull;
@@ -528,14 +532,15 @@ __global__ __launch_bounds__(64) void k_gapped_fast(GapView v, pgx_hit *__restri
 					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
 					if (item < n_it) {
 						const uint32_t slot = atomicAdd(&lds.bucket[(v.key[p - table] >> (4 * side)) & 15u], 1u);
-						lds.order[slot] = (uint16_t)item;
+						__hip_atomic_store(&order[slot], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
 				}
 				lds_sync();
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the order array is in L2 before any lane reads it back
 				// ---- 64 sides of similar cost per round
 				for (uint32_t it = 0; it < n_it; it += 64) {
 					const bool mine = it + lane < n_it;
-					const uint32_t item = lds.order[mine ? it + lane : n_it - 1];
+					const uint32_t item = __hip_atomic_load(&order[mine ? it + lane : n_it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					pgx_hit *hp = locate(chunk + item);
 					const size_t slot = (size_t)(hp - table);
 					pgx_hit h;
@@ -813,6 +818,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	PGX_TRY(gw.big_count.ensure(1));
 	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
 	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
+	PGX_TRY(gw.order.ensure((size_t)8192 * kBlkItems));
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
 	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
@@ -824,11 +830,11 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		v.key = main_key;                                                                                                            \
 		hipLaunchKernelGGL((k_gapped_fast<false, ML>), dim3(grid ? grid : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
-				   gw.side_main.data(), dbg);                                                                                        \
+				   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
 		v.key = ovf_key;                                                                                                             \
 		hipLaunchKernelGGL((k_gapped_fast<true, ML>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
 				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
-				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg);                                                              \
+				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
 	} while (0)
 	if (max_len <= 192)
 		PGX_GAPPED_LAUNCH(192);
