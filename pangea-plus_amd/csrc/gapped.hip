@@ -376,6 +376,14 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	// The first kGUnrollLevels levels as straight code: level d is the diagonals -d .. d, known when compiling, so they
 	// carry no tests at all (most sides of a 150-base read end within them); the later levels share one unrolled row
 	// whose diagonals are tested, in groups of kGGroup first, for "level d does not reach this one".
+	// After a level: can any cell of the next one pass the bound?  Its diagonals k must lie in
+	// (6 (d + 1) - slack_s, slack_q - 6 (d + 1)) and in [-(d + 1), d + 1]; when no lane has such a k the side ends here,
+	// without a level of dead cells to find that out (`best` only grows, so a lane that fails this fails it for good).
+	auto more = [&](int d) {
+		const int n6 = 6 * (d + 1);
+		const int lo = max(n6 - slack_s + 1, -(d + 1)), hi = min(slack_q - n6 - 1, d + 1);
+		return lo <= hi;
+	};
 	bool done = false;
 	static_for<1, kGUnrollLevels + 1>([&](auto dc) {
 		constexpr int d = decltype(dc)::value;
@@ -388,7 +396,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				GAP_STAT(3, 1);
 				GAP_STAT(7, __popcll(__ballot(live)));
 				static_for<C - d, C + d + 1>([&](auto cc) { cell(cc, 6 * d, std::integral_constant<int, d - 1>{}); });
-				live = any;
+				live = any && more(d);
 			}
 		}
 	});
@@ -412,7 +420,7 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				});
 			}
 		});
-		live = any;
+		live = any && more(d);
 	}
 	out.i = (int)best_cell >> 16;
 	out.j = out.i - best_k;
