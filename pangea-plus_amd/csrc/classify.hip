@@ -393,13 +393,16 @@ __device__ __forceinline__ pgx_hit unpack_hit(const uint4 c, uint32_t read)
 
 // Spec v2: what the seed stage hands to the gapped stage is not a hit but a SEED RECORD in the same 32 bytes, holding
 // what a round of the gapped kernel needs without a second look-up: read, subject, qstart = word offset of the read,
-// qend = anchor (read position on the hit's strand), sstart = database position of the anchor, send = strand,
-// score = read length, mismatch / gapopen = mismatches of the diagonal left / right of the anchor (capped at 15).
-// Staged 16-byte form (two short reads per wavefront): subject, database position, anchor | strand << 31, estimates.
+// qend = anchor (read position on the hit's strand), sstart = database position of the anchor, send = strand | B0 of
+// the left side << 1 | B0 of the right side << 12 (11 bits each, see process_candidate), score = read length,
+// mismatch / gapopen = levels the gapped stage will run left / right of the anchor (capped at 15).
+// Staged 16-byte form (two short reads per wavefront): subject, database position, anchor | B0 left << 15 | strand << 31,
+// estimates | B0 right << 8.
 __device__ __forceinline__ uint4 pack_seed(const pgx_hit &h)
 {
-	return make_uint4((uint32_t)h.subject, (uint32_t)h.sstart, (uint32_t)h.qend | ((uint32_t)h.send << 31),
-			  (uint32_t)h.mismatch | ((uint32_t)h.gapopen << 4));
+	const uint32_t sd = (uint32_t)h.send; // strand | B0 left << 1 | B0 right << 12
+	return make_uint4((uint32_t)h.subject, (uint32_t)h.sstart, (uint32_t)h.qend | (((sd >> 1) & 0x7FFu) << 15) | (sd << 31),
+			  (uint32_t)h.mismatch | ((uint32_t)h.gapopen << 4) | ((sd >> 12) << 8));
 }
 
 __device__ __forceinline__ pgx_hit unpack_seed(const uint4 c, uint32_t read, uint32_t woff, int L)
@@ -408,9 +411,9 @@ __device__ __forceinline__ pgx_hit unpack_seed(const uint4 c, uint32_t read, uin
 	h.read = (int32_t)read;
 	h.subject = (int32_t)c.x;
 	h.qstart = (int32_t)woff;
-	h.qend = (int32_t)(c.z & 0x7FFFFFFFu);
+	h.qend = (int32_t)(c.z & 0x7FFFu);
 	h.sstart = (int32_t)c.y;
-	h.send = (int32_t)(c.z >> 31);
+	h.send = (int32_t)((c.z >> 31) | (((c.z >> 15) & 0x7FFu) << 1) | ((c.w >> 8) << 12));
 	h.score = L;
 	h.mismatch = (uint16_t)(c.w & 15u);
 	h.gapopen = (uint16_t)((c.w >> 4) & 15u);
@@ -641,14 +644,31 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 					q--; // (bl is a match)
 				int anchor = M.last_lt(q) + 1;
 				anchor = anchor > bl ? anchor : bl;
-				const int ml = M.count_range(D.lo, anchor), mr = M.count_range(anchor, D.hi);
+				// B0 of either side: a doubled score, 2 (letters) - 6 (mismatches), that the gapped stage is sure to reach on
+				// the anchor's own diagonal with at most 18 mismatches, which it prunes with from its first cell on.  The
+				// ungapped extension above scores a letter +1 / -2, i.e. +2 / -4 doubled -- the same as a matched / mismatched
+				// letter there -- so its ends bl, br ARE the best prefixes unless the drop-off of 10 stopped it early (then the
+				// bound is only lower, never wrong).  From it the number of LEVELS that stage will run on the side,
+				// floor((2 letters of the read on the side - B0) / 5): the work estimate its rounds are ordered by.
+				int b0l = 0, b0r = 0, kl = 15, kr = 15;
+				if constexpr (Mask::kHasWindows) {
+					const int ml = M.count_range(bl, anchor), mr = M.count_range(anchor, br + 1);
+					b0l = ml <= 18 ? 2 * (anchor - bl) - 6 * ml : 0;
+					b0r = mr <= 18 ? 2 * (br + 1 - anchor) - 6 * mr : 0;
+					b0l = b0l > 0 && b0l < 2047 ? b0l : 0; // (11 bits in the record; 0 = no bound)
+					b0r = b0r > 0 && b0r < 2047 ? b0r : 0;
+					kl = (2 * anchor - b0l) / 5;
+					kr = (2 * (L - anchor) - b0r) / 5;
+					kl = kl < 15 ? kl : 15;
+					kr = kr < 15 ? kr : 15;
+				}
 				h.qstart = (int32_t)woff;
 				h.qend = anchor;
 				h.sstart = (int32_t)(uint32_t)(D.dstart + anchor);
-				h.send = strand;
+				h.send = strand | (b0l << 1) | (b0r << 12);
 				h.score = L;
-				h.mismatch = (uint16_t)(ml < 15 ? ml : 15);
-				h.gapopen = (uint16_t)(mr < 15 ? mr : 15);
+				h.mismatch = (uint16_t)kl;
+				h.gapopen = (uint16_t)kr;
 			}
 			if (PGX_DBG_STOP(db) != 7)
 				emit(h);

@@ -167,6 +167,7 @@ struct GapView {
 // the seed record of the seed stage (classify.hip: pack_seed): everything a round needs except the subject's ends
 struct Anchor {
 	int strand, L, qa, sa, slen;
+	int b0l, b0r; // B0 of the two sides as the seed stage found them on the diagonal's mismatch flags (0: none given)
 	int64_t S0;
 	uint32_t gpos; // database position of the anchor
 	GapSeqs s;
@@ -175,7 +176,9 @@ struct Anchor {
 __device__ __forceinline__ Anchor anchor_of(const GapView &v, const pgx_hit &h)
 {
 	Anchor a;
-	a.strand = h.send;
+	a.strand = h.send & 1;
+	a.b0l = (h.send >> 1) & 0x7FF;
+	a.b0r = (h.send >> 12) & 0x7FF;
 	a.L = h.score;
 	a.qa = h.qend;
 	a.gpos = (uint32_t)h.sstart;
@@ -225,14 +228,15 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // parent that wins ties (this diagonal, then k - 1, then k + 1) and that parent's statistics together.
 //
 // A second cut, also unable to change the result while no X-drop test is made (d < kGLag: every score then passes it):
-// B0 = the best score of the path that never leaves the anchor's diagonal, found first with a walk over its mismatches.
+// B0 = the best score of the path that never leaves the anchor's diagonal (at most 18 mismatches).  The SEED stage
+// finds it on the diagonal's mismatch flags, which it holds anyway, and hands it over in the seed record together with
+// the number of levels the side will take, floor((2 M - B0) / 5), by which the rounds are ordered (a walk here cost a
+// twentieth of the kernel; ordering by the diagonal's mismatch count left the level counts of a round uneven).
 // That path is among the cells of the literal algorithm, so the final best is >= B0; a cell whose bound is BELOW B0 can
 // neither reach the final best nor tie it, its children's bounds are lower still, and no surviving cell has such a
 // parent.  A side that is still alive at d = kGLag goes to the wide kernel, which makes the X-drop tests.
 // Returns false for a lane whose cells are still alive after kGFastD differences.
-__device__ __forceinline__ int sext16(uint32_t c) { return (int)(int16_t)(uint16_t)c; }
-
-__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int q0, int d0, int M, int N, Side &out)
+__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int q0, int d0, int M, int N, int b0, Side &out)
 {
 	int slide_rounds = 0;
 	(void)slide_rounds;
@@ -261,29 +265,6 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	out.i = out.j = i0;
 	out.s2 = 2 * i0;
 	bool live = on && !(i0 == M || i0 == N); // this lane still has cells to explore
-	// B0: the anchor's diagonal alone (mismatch, slide, mismatch, ...), as far as both sequences go
-	int b0 = 2 * i0;
-	{
-		int wi = i0, wd = 0;
-		bool walking = live;
-		while (__ballot(walking) != 0ull) {
-			GAP_STAT(6, 1);
-			if (walking) {
-				wd++;
-				wi++;
-				int wj = wi;
-				if (wi > M || wi > N || wd >= kGLag) {
-					walking = false;
-				} else {
-					slide(wi, wj);
-					const int s2 = 2 * wi - 6 * wd;
-					b0 = s2 > b0 ? s2 : b0;
-					if (wi == M || wi == N)
-						walking = false;
-				}
-			}
-		}
-	}
 	uint32_t R[kGFastCells];
 #pragma unroll
 	for (int c = 0; c < kGFastCells; c++)
@@ -555,7 +536,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 					h.read = h.subject = h.qstart = h.qend = h.sstart = h.send = h.score = 0;
 					h.mismatch = h.gapopen = 0;
 					Anchor a;
-					a.strand = a.L = a.qa = a.sa = a.slen = 0;
+					a.strand = a.L = a.qa = a.sa = a.slen = a.b0l = a.b0r = 0;
 					a.S0 = 0;
 					a.gpos = 0;
 					a.s.rw = a.s.ra = a.s.dbw = a.s.dba = nullptr;
@@ -627,7 +608,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 						lds_sync();
 						continue; // (probe: ordering + staging only)
 					}
-					ok = greedy_rows(rdw, dbwin, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, sd);
+					ok = greedy_rows(rdw, dbwin, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd);
 					if (mine) {
 						if (side == 0) {
 							// parked: i | j << 10 | mismatches << 20 | gap openings << 25 ; gap columns | wide << 31
