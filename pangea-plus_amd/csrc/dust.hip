@@ -8,8 +8,15 @@
 // The mask only removes SEEDS: what the seed stage reads is, per strand, one bit per read position i that says "the 28
 // bases from i on touch no masked base" (`d_dustwin_f`, `d_dustwin_r`; 64 positions per word at the read's word offset).
 //
-// k_dust_mask     one lane per read: the dynamic programme over (first triplet a descending, last triplet b ascending)
-//                 with the triplet counts, the row below and the current row (best sub-interval scores) in LDS
+// k_dust_trigger  one lane per read, linear: the published algorithm's own bookkeeping (window of the last 62 triplets with
+//                 its pair count r_w; its longest suffix in which no triplet occurs more than 4 times, of L triplets)
+//                 and its test "10 r_w > 20 L", without which that algorithm never looks for a perfect interval ending
+//                 at the position.  Reads that never pass it have no masked base (93 % of random 150-base reads;
+//                 the checker's fuzz of the test against the definition: oracle/fuzz_dust.c); the others are listed
+//                 with the first and last position that passed.
+// k_dust_mask     one lane per LISTED read: the definition itself, a dynamic programme over (first triplet a descending,
+//                 last triplet b ascending) restricted to intervals that end at or before the last such position and
+//                 start at most 61 triplets before the first; triplet counts and one row of best sub-interval scores in LDS
 // k_dust_windows  one lane per (read, 64 positions): the window bits of both strands from the mask
 #include "bitops.hpp"
 #include "engine.hpp"
@@ -20,7 +27,7 @@ constexpr int kDustMaxT = 62, kDustLevel = 20;
 
 struct DustLane {
 	uint8_t cnt[64];
-	uint32_t row[2][kDustMaxT + 2]; // score r | (triplets - 1) << 16; 0 = no score
+	uint32_t row[kDustMaxT + 2]; // score r | (triplets - 1) << 16; 0 = no score
 };
 
 __device__ __forceinline__ bool frac_gt(uint32_t a, uint32_t b) // a > b; "no score" is below every score
@@ -33,49 +40,114 @@ __device__ __forceinline__ bool frac_gt(uint32_t a, uint32_t b) // a > b; "no sc
 	return (a & 0xFFFFu) * bq > (b & 0xFFFFu) * aq;
 }
 
+// triplet value at position i of a packed read, or -1 (6 bits of the packed read; ambiguity flags of its three letters)
+__device__ __forceinline__ int dust_triplet(const uint64_t *rw, const uint64_t *ra, int i)
+{
+	const uint64_t w = window64(rw, i);
+	if (ra && (window64(ra, i) & 0x15ull))
+		return -1;
+	return (int)(((w & 3ull) << 4) | (((w >> 2) & 3ull) << 2) | ((w >> 4) & 3ull));
+}
+
+struct TrigLane {
+	uint8_t cw[64], cv[64];
+};
+
+__global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
+						      const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
+						      uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
+{
+	__shared__ TrigLane s_lane[64];
+	TrigLane &ld = s_lane[threadIdx.x];
+	const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+	if (r >= n)
+		return;
+	const int nt = (int)len[r] - 2;
+	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
+	uint32_t *c32 = reinterpret_cast<uint32_t *>(&ld);
+	for (int k = 0; k < 32; k++)
+		c32[k] = 0u;
+	int first = -1, last = -1;
+	int size = 0, L = 0, rw_pairs = 0, rv_pairs = 0; // the window is the `size` triplets that end at the current one
+	for (int b = 0; b < nt; b++) {
+		const int t = dust_triplet(rw, ra, b);
+		if (t < 0) { // a letter that is no base: no interval crosses it
+			for (int k = 0; k < 32; k++)
+				c32[k] = 0u;
+			size = L = rw_pairs = rv_pairs = 0;
+			continue;
+		}
+		if (size >= kDustMaxT) {
+			const int s0 = dust_triplet(rw, ra, b - size); // the oldest triplet leaves
+			size--;
+			rw_pairs -= --ld.cw[s0];
+			if (L > size) {
+				L--;
+				rv_pairs -= --ld.cv[s0];
+			}
+		}
+		size++;
+		L++;
+		rw_pairs += ld.cw[t]++;
+		rv_pairs += ld.cv[t]++;
+		if (ld.cv[t] * 10 > 2 * kDustLevel) {
+			int s0;
+			do { // the suffix shrinks past the earliest copy of t
+				s0 = dust_triplet(rw, ra, b - L + 1);
+				rv_pairs -= --ld.cv[s0];
+				L--;
+			} while (s0 != t);
+		}
+		if (rw_pairs * 10 > L * kDustLevel) {
+			first = first < 0 ? b : first;
+			last = b;
+		}
+	}
+	if (first >= 0) {
+		const uint32_t at = atomicAdd(n_list, 1u);
+		list[at] = r;
+		range[at] = make_uint2((uint32_t)first, (uint32_t)last);
+	}
+}
+
 __global__ __launch_bounds__(64) void k_dust_mask(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
-						   const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
+						   const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff,
+						   const uint32_t *__restrict__ list, const uint2 *__restrict__ range, const uint32_t *__restrict__ n_list,
 						   uint64_t *__restrict__ mask, uint8_t *__restrict__ any)
 {
 	__shared__ DustLane s_lane[64];
 	DustLane &ld = s_lane[threadIdx.x];
-	const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-	if (r >= n)
+	const uint32_t at = blockIdx.x * 64u + threadIdx.x;
+	if (at >= *n_list)
 		return;
+	const uint32_t r = list[at];
 	const int L = (int)len[r], nt = L - 2;
 	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
 	uint64_t *mw = mask + woff[r];
 	bool marked = false;
-	if (nt < 2) {
-		any[r] = 0;
-		return;
-	}
-	// triplet value at position i, or -1 (6 bits of the packed read; ambiguity flags of its three letters)
-	auto triplet = [&](int i) -> int {
-		const uint64_t w = window64(rw, i);
-		if (ra && (window64(ra, i) & 0x15ull))
-			return -1;
-		return (int)(((w & 3ull) << 4) | (((w >> 2) & 3ull) << 2) | ((w >> 4) & 3ull));
-	};
-	int below = 0;
+	// perfect intervals end at a position that passed the trigger: [b_first, b_last]; they hold at most 62 triplets
+	const int b_hi = (int)range[at].y, a_lo = (int)range[at].x - (kDustMaxT - 1) > 0 ? (int)range[at].x - (kDustMaxT - 1) : 0;
+	auto triplet = [&](int i) -> int { return dust_triplet(rw, ra, i); };
 	for (int k = 0; k < kDustMaxT + 2; k++)
-		ld.row[0][k] = ld.row[1][k] = 0u;
-	for (int a = nt - 1; a >= 0; a--) {
+		ld.row[k] = 0u;
+	// one row, updated in place: before the step for (a, b) row[b - a] holds the best of [a + 1, b + 1] and row[b - a - 1]
+	// the best of [a + 1, b] (the row below); the step leaves the best of [a, b] in row[b - a]
+	for (int a = b_hi < nt - 1 ? b_hi : nt - 1; a >= a_lo; a--) {
 		for (int k = 0; k < 16; k++)
 			reinterpret_cast<uint32_t *>(ld.cnt)[k] = 0u;
-		uint32_t *rb = ld.row[below], *rc = ld.row[below ^ 1];
-		uint32_t rsum = 0, left = 0u;
+		uint32_t rsum = 0, left = 0u, below_prev = 0u; // below_prev = row below at index b - a - 1 (saved before it is overwritten)
 		int b = a;
-		for (; b < nt && b - a < kDustMaxT; b++) {
+		for (; b <= b_hi && b < nt && b - a < kDustMaxT; b++) {
 			const int t = triplet(b);
 			if (t < 0)
 				break;
 			rsum += ld.cnt[t]++;
 			const uint32_t q = (uint32_t)(b - a);
 			const uint32_t s = q ? (rsum | (q << 16)) : 0u;
+			const uint32_t old_here = ld.row[b - a]; // row below at index b - a: the next step's `below_prev`
 			uint32_t sub = left;
-			if (b > a && frac_gt(rb[b - a - 1], sub))
-				sub = rb[b - a - 1];
+			if (b > a && frac_gt(below_prev, sub))
+				sub = below_prev;
 			if (q && rsum * 10u > (uint32_t)kDustLevel * q && !frac_gt(sub, s)) {
 				// mask bases a .. b + 2 (this lane's own words)
 				marked = true;
@@ -88,12 +160,12 @@ __global__ __launch_bounds__(64) void k_dust_mask(const uint64_t *__restrict__ f
 				}
 			}
 			const uint32_t best = frac_gt(s, sub) ? s : sub;
-			rc[b - a] = best;
+			ld.row[b - a] = best;
 			left = best;
+			below_prev = old_here;
 		}
 		for (int k = b - a; k <= kDustMaxT; k++)
-			rc[k] = 0u;
-		below ^= 1;
+			ld.row[k] = 0u;
 	}
 	any[r] = marked ? 1 : 0;
 }
@@ -109,28 +181,54 @@ __global__ void k_dust_windows(const uint64_t *__restrict__ mask, const uint8_t 
 	const int L = (int)len[r];
 	const uint32_t w0 = woff[r];
 	const int nw = (L + 63) >> 6;
+	const int n_valid = L - kWord + 1; // window positions 0 .. n_valid - 1
 	const bool dirty = any[r] != 0;
-	auto masked = [&](int i) { return (mask[w0 + (i >> 6)] >> (i & 63)) & 1ull; };
+	auto valid_bits = [&](int w) -> uint64_t { // positions of word w below n_valid
+		const int left = n_valid - (w << 6);
+		return left <= 0 ? 0ull : (left >= 64 ? ~0ull : ((1ull << left) - 1ull));
+	};
 	for (int w = 0; w < nw; w++) {
-		uint64_t f = 0, rv = 0;
-		for (int k = 0; k < 64; k++) {
-			const int i = (w << 6) + k;
-			if (i + kWord > L)
-				break;
-			if (!dirty) {
-				f |= 1ull << k;
-				rv |= 1ull << k;
-				continue;
-			}
-			bool cf = true, cr = true;
-			for (int j = 0; j < kWord && (cf || cr); j++) {
-				cf = cf && !masked(i + j);
-				cr = cr && !masked(L - 1 - (i + j));
-			}
-			f |= cf ? 1ull << k : 0ull;
-			rv |= cr ? 1ull << k : 0ull;
+		uint64_t f = valid_bits(w);
+		if (dirty) {
+			// a window is spoilt by a masked base at any of its 28 positions: OR of the mask moved down by 0 .. 27, in log
+			// steps on the 128 bits that start at this word (2, 4, 8, 16 wide, then 16 + 8 + 4)
+			uint64_t lo = mask[w0 + w], hi = w + 1 < nw ? mask[w0 + w + 1] : 0ull;
+			auto shr = [](uint64_t &a, uint64_t &b, int k) { // (a, b) |= (a, b) >> k
+				a |= (a >> k) | (b << (64 - k));
+				b |= b >> k;
+			};
+			shr(lo, hi, 1);
+			const uint64_t l2 = lo, h2 = hi; // covers 2
+			shr(lo, hi, 2);
+			const uint64_t l4 = lo, h4 = hi; // covers 4
+			shr(lo, hi, 4);
+			const uint64_t l8 = lo, h8 = hi; // covers 8
+			shr(lo, hi, 8); // covers 16
+			(void)l2;
+			(void)h2;
+			const uint64_t d = lo | ((l8 >> 16) | (h8 << 48)) | ((l4 >> 24) | (h4 << 40)); // 16 + 8 + 4 = 28
+			f &= ~d;
 		}
 		win_f[w0 + w] = f;
+	}
+	// the reverse-complement strand: its window i is the forward window n_valid - 1 - i
+	for (int w = 0; w < nw; w++) {
+		uint64_t rv = valid_bits(w);
+		if (dirty) {
+			// forward positions n_valid - 64 w - 64 .. n_valid - 64 w - 1, reversed
+			const int s0 = n_valid - (w << 6) - 64;
+			uint64_t span;
+			if (s0 >= 0) {
+				const int wi = s0 >> 6, sh = s0 & 63;
+				const uint64_t a = win_f[w0 + wi], b = (sh && wi + 1 < nw) ? win_f[w0 + wi + 1] : 0ull;
+				span = sh ? (a >> sh) | (b << (64 - sh)) : a;
+			} else if (s0 > -64) {
+				span = win_f[w0] << (-s0);
+			} else {
+				span = 0ull;
+			}
+			rv = __brevll(span);
+		}
 		win_r[w0 + w] = rv;
 	}
 }
@@ -146,10 +244,24 @@ int reads_dust(pgx_reads *rd)
 	DevBuf<uint8_t> &d_any = rd->d_dust_any;
 	PGX_TRY(d_mask.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	PGX_TRY(d_any.alloc(n));
-	hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(),
-			   rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr, rd->d_len.data(), rd->d_woff.data(), (uint32_t)n,
-			   d_mask.data(), d_any.data());
+	PGX_HIP(hipMemsetAsync(d_any.data(), 0, n, 0));
+	DevBuf<uint32_t> d_list, d_nlist;
+	DevBuf<uint2> d_range;
+	PGX_TRY(d_list.alloc(n));
+	PGX_TRY(d_range.alloc(n));
+	PGX_TRY(d_nlist.alloc(1));
+	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, sizeof(uint32_t), 0));
+	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
+	hipLaunchKernelGGL(k_dust_trigger, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
+			   rd->d_woff.data(), (uint32_t)n, d_list.data(), d_range.data(), d_nlist.data());
 	PGX_HIP(hipGetLastError());
+	uint32_t n_listed = 0;
+	PGX_TRY(d_nlist.download(&n_listed, 1));
+	if (n_listed) {
+		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
+				   rd->d_woff.data(), d_list.data(), d_range.data(), d_nlist.data(), d_mask.data(), d_any.data());
+		PGX_HIP(hipGetLastError());
+	}
 	std::vector<uint8_t> &h_any = rd->h_read_dust;
 	h_any.resize(n);
 	PGX_TRY(d_any.download(h_any.data(), n));

@@ -570,3 +570,14 @@ def test_synthetic_workload_shape(oracle_bin, tmp_path):
         assert rid == "r%d" % i
         f = rest.split("\t")
         assert len(f) % 3 == 0 and set(f[1::3]) <= {"domain", "phylum", "class", "order", "family", "genus"}
+
+
+def test_dust_trigger_is_necessary_for_a_masked_base():
+    """The device runs the DUST definition only on reads in which the published algorithm's own trigger (10 r_w > 20 L) fires
+    somewhere (csrc/dust.hip).  oracle/fuzz_dust.c: no read with a masked base (definition, o_dust.c) lacks a trigger."""
+    import subprocess
+    from conftest import ORACLE_DIR
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "bin/fuzz_dust"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(ORACLE_DIR, "bin", "fuzz_dust"), "60000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "counterexamples 0" in p.stdout
