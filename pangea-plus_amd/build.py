@@ -6,6 +6,7 @@ both travel to the GPU box with the gpurun snapshot).
 """
 import concurrent.futures
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -20,6 +21,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libpangea_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+BASE_FLAGS = list(FLAGS)
 if os.environ.get("PGX_STAGE_PROBES"):  # measurement builds only: kernels that can be truncated after a stage
     FLAGS.append("-DPGX_STAGE_PROBES")
 FLAGS += os.environ.get("PGX_EXTRA_FLAGS", "").split()  # experiments (-D switches of the kernels under study)
@@ -40,7 +42,9 @@ def _newer(src, dst, extra=()):
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    # (objects of a build with other -D switches -- measurement builds -- get their own names, so neither build is stale)
+    tag = "" if FLAGS == BASE_FLAGS else "." + hashlib.md5(" ".join(FLAGS).encode()).hexdigest()[:8]
+    obj = os.path.join(OBJDIR, os.path.basename(src) + tag + ".o")
     headers = tuple(glob.glob(os.path.join(CSRC, "*.hpp"))) + (os.path.join(HERE, "..", "include", "pangea_hip.h"),)
     if _newer(src, obj, headers):
         cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
@@ -50,17 +54,26 @@ def _compile(src):
     return obj
 
 
+def _last_link():
+    try:
+        return open(os.path.join(OBJDIR, "linked.txt")).read().split("\n")
+    except OSError:
+        return None
+
+
 def build_library(verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    if any(_newer(o, LIB) for o in objs):
+    if any(_newer(o, LIB) for o in objs) or _last_link() != objs:
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)
+        with open(os.path.join(OBJDIR, "linked.txt"), "w") as f:
+            f.write("\n".join(objs))
     if verbose:
         print("built", LIB)
     return LIB
