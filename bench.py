@@ -326,13 +326,24 @@ def main():
                          "survey_8d": survey_8d(last.hits / B, world * B * args.steps / dt / world), "random_line_roof": line_roof}
             if gap_ms > kernel_ms:
                 # spec v2: the gapped stage is the longest kernel of the step.  It is integer work on letters held in LDS and
-                # registers (no MFMA; ~75 vector instructions per cell of the greedy recurrence), so its share of the HBM
-                # roof is small by nature; the line says so instead of hiding the kernel behind the seed stage's
+                # registers (no MFMA; ~45 vector instructions per cell of the greedy recurrence), so its share of the HBM
+                # roof is small by nature; the line says so instead of hiding the kernel behind the seed stage's.  What
+                # bounds it is instruction issue: `issue` = vector instructions per launch (PMC, profiles/) x 4 cycles /
+                # (1024 SIMDs x the launch's cycles at 2.4 GHz), scaled from the PMC run's 1 M reads to this launch
                 g_ach = gap_bytes / (gap_ms * 1e-3) / 1e9
+                issue = None
+                try:
+                    valu_per_read = json.load(open(tp)).get("k_gapped_fast_valu_instructions_per_read")
+                    if valu_per_read:
+                        busy = valu_per_read * B * 4.0 / (1024 * 2.4e9 * (gap_ms / args.steps) * 1e-3)
+                        issue = {"valu_instructions_per_read": valu_per_read, "valu_busy_frac_at_2.4GHz": busy,
+                                 "basis": "SQ_INSTS_VALU of k_gapped_fast per read (profiles/r02_gapped_instruction_mix.txt) x reads x 4 cycles / (1024 SIMDs x kernel time)"}
+                except Exception:
+                    issue = None
                 out["roofline"] = {"bound": "hbm", "kernel": "k_gapped_fast (+ k_gapped_big)", "achieved": g_ach, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": gap_traffic,
                                    "alg_bytes_per_launch": gap_bytes / args.steps, "kernel_ms_per_launch": gap_ms / args.steps,
-                                   "note": "bound by vector issue, not by memory: see DESIGN.md section 7",
+                                   "note": "bound by instruction issue, not by memory: see DESIGN.md section 7", "issue": issue,
                                    "seed_extend": seed_roof}
             else:
                 out["roofline"] = seed_roof

@@ -288,6 +288,14 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		constexpr int k = c - C;
 		constexpr int reach = decltype(reach_c)::value;
 		const uint32_t cur = R[c], nxt = R[c + 1];
+		// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers; when
+		// no lane passes it (the dead half of a side's last levels) the cell is dead for the whole wavefront
+		const bool can = (slack_q > six_d + k) & (slack_s > six_d - k);
+		if (__ballot(can) == 0ull) {
+			prev = cur;
+			R[c] = kCellNone;
+			return;
+		}
 		int m3;
 		if constexpr (k - 1 < -reach && k > reach) // (level 1, k = +1 handled below; this is never true)
 			m3 = (int)kCellNone;
@@ -306,10 +314,9 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		const int v = m3 >> 16;
 		const uint32_t kind = 2u - (((uint32_t)m3 >> 14) & 3u); // 0: mismatch on this diagonal, 1: from k - 1, 2: from k + 1
 		const int jj0 = v - k;
-		// the bound min(2 M - k, 2 N + k) - 6 d > best, as two tests of per-lane slacks against wave-uniform numbers
 		// (a lane that is not live holds a row of dead cells -- every cell of its last level was written dead -- so it
 		// needs no test of its own: v is -32768 there)
-		const bool alive = ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & (slack_q > six_d + k) & (slack_s > six_d - k);
+		const bool alive = ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & can;
 		uint32_t nc = kCellNone;
 		GAP_STAT(0, 1);
 		GAP_STAT(1, __popcll(__ballot(alive)));
