@@ -1412,11 +1412,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		pgx_hit h;
 		h.subject = h.score = h.qstart = h.qend = h.sstart = h.send = h.read = 0;
 		h.mismatch = h.gapopen = 0;
-		if (mine) {
+		if (mine)
 			h = src[li];
-			sw->a.subj[slot0 + li] = h.subject;
-			sw->a.score[slot0 + li] = h.score;
-		}
+		// (rows past the read's end hold a subject no hit has, so the loops below need no "j < n" of their own)
+		sw->a.subj[slot0 + li] = mine ? h.subject : -1;
+		sw->a.score[slot0 + li] = h.score;
 		// the read's RDP codes (slots past the end match nothing)
 		uint32_t rcode[kRdpRegs], rdp0 = 0, rdp1 = 0;
 		if (do_consensus && n) {
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 #pragma unroll
 			for (int u = 0; u < 4; u++)
-				if (j0 + u < n && sj[u] == h.subject) {
+				if (sj[u] == h.subject) {
 					same_subj++;
 					if (sc[u] > best)
 						best = sc[u];
@@ -1465,8 +1465,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			}
 			continue;
 		}
+		sw->a.k1[slot0 + li] = mine ? kx.k1 : ~0ull; // (past the end: a key that precedes none and equals none)
 		if (mine) {
-			sw->a.k1[slot0 + li] = kx.k1;
 			sw->a.k2[slot0 + li] = kx.k2;
 			sw->a.send[slot0 + li] = kx.send;
 			sw->a.mg[slot0 + li] = kx.mg;
@@ -1506,16 +1506,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		// score, subject, score): count on that word alone, and compare second words only inside groups of equal
 		// first words (several HSPs of one subject with one score), which most reads do not have.
 		uint32_t rank = 0, same = 0;
-		for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
-			uint64_t a1[4];
+		if (drop_mask == 0ull) { // the usual wavefront: nothing was dropped, rows past a read's end hold the last key
+			for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
+				uint64_t a1[4];
 #pragma unroll
-			for (int u = 0; u < 4; u++)
-				a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
+				for (int u = 0; u < 4; u++)
+					a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
 #pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const bool in = (j0 + u < n_all) & !((drop_mask >> (slot0 + ((j0 + u) & (G - 1)))) & 1ull);
-				rank += (in & (a1[u] < kx.k1)) ? 1u : 0u;
-				same += (in & (a1[u] == kx.k1)) ? 1u : 0u;
+				for (int u = 0; u < 4; u++) {
+					rank += a1[u] < kx.k1 ? 1u : 0u;
+					same += a1[u] == kx.k1 ? 1u : 0u;
+				}
+			}
+		} else {
+			for (uint32_t j0 = 0; j0 < nmax; j0 += 4) {
+				uint64_t a1[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					a1[u] = sw->a.k1[slot0 + ((j0 + u) & (G - 1))];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					const bool in = (j0 + u < n_all) & !((drop_mask >> (slot0 + ((j0 + u) & (G - 1)))) & 1ull);
+					rank += (in & (a1[u] < kx.k1)) ? 1u : 0u;
+					same += (in & (a1[u] == kx.k1)) ? 1u : 0u;
+				}
 			}
 		}
 		if (__ballot(kept && same > 1u)) {
