@@ -10,12 +10,12 @@
 // are stated in DESIGN.md (spec v2) and restated by the checker in oracle/o_gapped.c.
 //
 // Two kernels, the same results:
-//   k_gapped_fast  one LANE per HSP (reads of <= 512 bases, <= 15 differences per side): the R row of the lane lives in
-//                  33 LDS words and is updated in place (k ascending, the two neighbours carried in registers); a cell
-//                  carries its own statistics (mismatches, gap openings, kind of the last column), so there is no
-//                  traceback.  HSPs that need more go on a list.
+//   k_gapped_fast  one LANE per HSP side (reads of <= 512 bases, <= 18 differences per side): loops over the difference
+//                  count d and the diagonal k are shared by the 64 lanes, the row R(d, .) of a lane is 39 registers
+//                  updated in place; a cell carries its own statistics (mismatches, gap openings, open-gap kind), so
+//                  there is no traceback.  Sides that need more go on a list.
 //   k_gapped_big   one WAVEFRONT per listed HSP, one lane per diagonal (64 at a time, <= 1000 differences per side), rows
-//                  double-buffered in LDS.
+//                  double-buffered in LDS, the X-drop history, ambiguity flags.
 // Both cut a cell whose score could not pass the best one even if every remaining letter matched.  The cut cannot change
 // the result (a child's bound is below its parent's, so no surviving cell has a cut parent; a cut cell never holds the
 // best score), which is why the sequential kernel, the parallel one (bound taken one step late) and the checker (no
@@ -110,16 +110,14 @@ template <int DIR> __device__ __forceinline__ int lcp(const GapSeqs &s, int qp, 
 
 // ------------------------------------------------------------------------------------------ one lane per HSP
 // Work per HSP is quadratic in its differences and varies a lot (0 to ~500 cells).  History of this kernel, 10 M reads
-// (282 M HSPs) per launch: nested per-lane loops, sequences read through the caches: 1 080 ms with a 15-difference limit
-// (3.6 % of the HSPs fell to the wide kernel); a per-lane state machine with dynamic refill (one cell per lane per trip):
-// 340 ms, then 713 ms with the sequences in LDS at 1.75 waves per SIMD -- 470 vector instructions per trip, almost all of
-// it bookkeeping of a state machine whose rare per-lane events happen in some lane on every trip.  Now: the loops over d
-// and k are WAVE-UNIFORM, which lets the row of a lane live in registers, and a wavefront first orders its HSPs by the
-// seed stage's work estimate so that the 64 lanes of a round have about the same number of rows.
-// The two sequences of a lane's HSP are staged in LDS when the lane takes it (read strand; database window around the
-// anchor: read length + 2 x kGFastD + slack bases): fetched from the caches per cell, 64 lanes x 2 lines each, they made the
-// kernel wait on L2 (first version: 340 ms per 10 M reads; 2.8 TB of line traffic).  HSPs that touch an ambiguity letter
-// (read or database window) go to the wide kernel, which applies the flag words.
+// (282 M HSPs) per launch (DESIGN.md section 7 has the table): nested per-lane loops, letters through the caches: 1 080 ms;
+// a per-lane state machine with dynamic refill: 340 ms (470 vector instructions per trip: every rare per-lane event
+// happens in some lane on every trip); WAVE-UNIFORM loops over d and k with the HSPs of a pool ordered by cost, the row in
+// registers, letters staged in LDS: 198 -> 124 ms; then the finding that a wavefront of this kernel is bound by its OWN
+// instruction issue (one instruction per 4 cycles whatever its type): scalar skip tests grouped and then compiled away for
+// the first levels, one forward-only copy of the row code (left sides staged reversed), parents by one signed maximum,
+// the bound as two compares, B0 and the level count handed over by the seed stage, 4 wavefronts per SIMD: 56 ms.
+// HSPs that touch an ambiguity letter (read or database window) go to the wide kernel, which applies the flag words.
 __device__ __forceinline__ uint32_t lds_window16(const uint32_t *w, int pos)
 {
 	const int i = pos >> 4;
