@@ -3,9 +3,11 @@
  * Checks the shortcut the device takes in spec S3d (csrc/dust.hip: k_dust_trigger) against the DEFINITION restated in
  * o_dust.c: the published algorithm (Morgulis et al. 2006) keeps, per position, the pair count r_w of the window of the last
  * 62 triplets and the length L of that window's longest suffix in which no triplet occurs more than 4 times, and only looks
- * for perfect intervals ending at the position when 10 r_w > 20 L.  The device lists the reads in which some position
- * passes that test and runs the definition on those alone.  This program generates reads (uniform, biased, with noisy
- * repeats of unit 1-6, with an N) and fails if a read with a masked base (definition) has no position that passes.
+ * for perfect intervals ending at the position when 10 r_w > 20 L; it then walks the suffixes longer than that suffix.
+ * The device does the same walk and lists a read when one of those suffixes scores above the level (an interval above the
+ * level exists exactly when a perfect one does: its best sub-interval), then runs the definition on the listed reads alone,
+ * between the first and last such position.  This program generates reads (uniform, biased, with noisy repeats of unit
+ * 1-6, with an N) and fails if a read with a masked base (definition) is not listed; it also prints how many are listed.
  * usage: fuzz_dust [reads]     (tests/test_oracle_classify.py runs it with 60 000)
  */
 #include <stdint.h>
@@ -37,7 +39,16 @@ static int dust_trigger(const uint8_t *base, int len)
 			int s;
 			do { s = w[(head + size - L) & 63]; rv -= --cv[s]; L--; } while (s != t);
 		}
-		if (rw * 10 > L * 20) trig = 1;
+		if (rw * 10 > L * 20) {
+			trig |= 1;
+			int c[64], r = rv;
+			memcpy(c, cv, sizeof c);
+			for (int k = size - L - 1; k >= 0; k--) {
+				int tt = w[(head + k) & 63];
+				r += c[tt]++;
+				if (r * 10 > 20 * (size - k - 1)) { trig |= 2; break; }
+			}
+		}
 	}
 	return trig;
 }
@@ -72,9 +83,12 @@ int main(int argc, char **argv)
 		int any = 0;
 		for (int i = 0; i < len; i++) any |= m[i];
 		int tr = dust_trigger(b, len);
-		nm += any; nt += tr;
-		if (kind == 0) { nu++; nm_u += any; nt_u += tr; }
-		if (any && !tr) {
+		nm += any; nt += tr & 1;
+		static long ns, ns_u;
+		ns += (tr >> 1) & 1;
+		if (kind == 0) { nu++; nm_u += any; nt_u += tr & 1; ns_u += (tr >> 1) & 1; }
+		if (it == n - 1) printf("strong: all %ld, uniform %ld\n", ns, ns_u);
+		if (any && !(tr & 2)) {
 			if (bad < 5) { printf("COUNTEREXAMPLE len %d: ", len); for (int i = 0; i < len; i++) putchar("ACGTN"[b[i]]); putchar('\n'); }
 			bad++;
 		}

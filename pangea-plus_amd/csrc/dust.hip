@@ -28,7 +28,9 @@ constexpr int kDustMaxT = 62, kDustLevel = 20;
 struct DustLane {
 	uint8_t cnt[64];
 	uint32_t row[kDustMaxT + 2]; // score r | (triplets - 1) << 16; 0 = no score
+	uint32_t pad;                // 81 words per lane (odd stride: see TrigLane)
 };
+static_assert(sizeof(DustLane) / 4 % 2 == 1, "odd word stride");
 
 __device__ __forceinline__ bool frac_gt(uint32_t a, uint32_t b) // a > b; "no score" is below every score
 {
@@ -50,18 +52,34 @@ __device__ __forceinline__ int dust_triplet(const uint64_t *rw, const uint64_t *
 }
 
 struct TrigLane {
-	uint8_t cw[64], cv[64];
+	uint8_t cw[64], cv[64], ct[64];
+	uint32_t pad; // 49 words per lane: an even word stride put the 64 lanes' counters on two LDS banks (32-way conflicts)
 };
+static_assert(sizeof(TrigLane) / 4 % 2 == 1, "odd word stride");
 
+// the trigger works on raw 6-bit triplet codes (any one-to-one naming of the 64 triplets counts the same pairs)
+__device__ __forceinline__ int dust_tid(const uint64_t *rw, const uint64_t *ra, int i)
+{
+	if (ra && (window64(ra, i) & 0x15ull))
+		return -1;
+	return (int)(window64(rw, i) & 63ull);
+}
+
+// CONFIRM = false: every read of the batch, the algorithm's own test only (a read that never passes it is done);
+// CONFIRM = true: the reads the first pass listed, packed 64 to a wavefront, with the walk over the longer suffixes at every
+// position that passes (kept out of the first pass: one lane walking there held up the other 63)
+template <bool CONFIRM>
 __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
 						      const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
+						      const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ n_in,
 						      uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
 {
 	__shared__ TrigLane s_lane[64];
 	TrigLane &ld = s_lane[threadIdx.x];
-	const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-	if (r >= n)
+	const uint32_t at0 = blockIdx.x * 64u + threadIdx.x;
+	if (at0 >= (CONFIRM ? *n_in : n))
 		return;
+	const uint32_t r = CONFIRM ? in_list[at0] : at0;
 	const int nt = (int)len[r] - 2;
 	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
 	uint32_t *c32 = reinterpret_cast<uint32_t *>(&ld);
@@ -69,8 +87,17 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 		c32[k] = 0u;
 	int first = -1, last = -1;
 	int size = 0, L = 0, rw_pairs = 0, rv_pairs = 0; // the window is the `size` triplets that end at the current one
+	// the entering and the leaving triplet come from two 64-bit registers that hold the next 32 letters each and move on
+	// by one letter per position (refilled every 16 positions); only the rare steps below go back to memory
+	uint64_t in_w = 0, out_w = 0;
+	int out_pos = -1;
 	for (int b = 0; b < nt; b++) {
-		const int t = dust_triplet(rw, ra, b);
+		if ((b & 15) == 0)
+			in_w = window64(rw, b);
+		int t = (int)(in_w & 63ull);
+		in_w >>= 2;
+		if (ra && (window64(ra, b) & 0x15ull))
+			t = -1;
 		if (t < 0) { // a letter that is no base: no interval crosses it
 			for (int k = 0; k < 32; k++)
 				c32[k] = 0u;
@@ -78,7 +105,15 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			continue;
 		}
 		if (size >= kDustMaxT) {
-			const int s0 = dust_triplet(rw, ra, b - size); // the oldest triplet leaves
+			// the oldest triplet leaves: position b - 62 (the window was full, so it is 62 triplets behind)
+			const int ob = b - kDustMaxT;
+			if (ob != out_pos || (ob & 15) == 0) {
+				out_w = window64(rw, ob);
+				out_pos = ob;
+			}
+			const int s0 = (int)(out_w & 63ull);
+			out_w >>= 2;
+			out_pos++;
 			size--;
 			rw_pairs -= --ld.cw[s0];
 			if (L > size) {
@@ -93,20 +128,48 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 		if (ld.cv[t] * 10 > 2 * kDustLevel) {
 			int s0;
 			do { // the suffix shrinks past the earliest copy of t
-				s0 = dust_triplet(rw, ra, b - L + 1);
+				s0 = dust_tid(rw, ra, b - L + 1);
 				rv_pairs -= --ld.cv[s0];
 				L--;
 			} while (s0 != t);
 		}
-		if (rw_pairs * 10 > L * kDustLevel) {
+		if (!CONFIRM && rw_pairs * 10 > L * kDustLevel) {
 			first = first < 0 ? b : first;
 			last = b;
 		}
+		if (CONFIRM && rw_pairs * 10 > L * kDustLevel) {
+			// the algorithm would now look at the suffixes LONGER than that suffix, longest last; an interval that scores
+			// above the level exists in the read exactly when one of these does somewhere (its best sub-interval is
+			// perfect), so this decides whether the read has a masked base at all
+			uint32_t *t32 = reinterpret_cast<uint32_t *>(ld.ct);
+			const uint32_t *v32 = reinterpret_cast<const uint32_t *>(ld.cv);
+			for (int k = 0; k < 16; k++)
+				t32[k] = v32[k];
+			int rr = rv_pairs;
+			for (int k = size - L - 1; k >= 0; k--) {
+				const int tt = dust_tid(rw, ra, b - size + 1 + k);
+				rr += ld.ct[tt]++;
+				if (rr * 10 > kDustLevel * (size - k - 1)) {
+					first = first < 0 ? b : first;
+					last = b;
+					break;
+				}
+			}
+		}
 	}
-	if (first >= 0) {
-		const uint32_t at = atomicAdd(n_list, 1u);
-		list[at] = r;
-		range[at] = make_uint2((uint32_t)first, (uint32_t)last);
+	// one atomic per wavefront (a single counter takes ~90 M atomics a second: one per listed read was most of this kernel)
+	const unsigned long long listed = __ballot(first >= 0);
+	if (listed) {
+		uint32_t base = 0;
+		const int leader = __ffsll((unsigned long long)listed) - 1;
+		if ((int)(threadIdx.x & 63) == leader)
+			base = atomicAdd(n_list, (uint32_t)__popcll(listed));
+		base = __shfl(base, leader);
+		if (first >= 0) {
+			const uint32_t at = base + (uint32_t)__popcll(listed & ((1ull << (threadIdx.x & 63)) - 1ull));
+			list[at] = r;
+			range[at] = make_uint2((uint32_t)first, (uint32_t)last);
+		}
 	}
 }
 
@@ -245,21 +308,30 @@ int reads_dust(pgx_reads *rd)
 	PGX_TRY(d_mask.alloc((size_t)rd->n_words + 24, 0, 0, true));
 	PGX_TRY(d_any.alloc(n));
 	PGX_HIP(hipMemsetAsync(d_any.data(), 0, n, 0));
-	DevBuf<uint32_t> d_list, d_nlist;
+	DevBuf<uint32_t> d_list, d_list2, d_nlist;
 	DevBuf<uint2> d_range;
 	PGX_TRY(d_list.alloc(n));
 	PGX_TRY(d_range.alloc(n));
-	PGX_TRY(d_nlist.alloc(1));
-	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, sizeof(uint32_t), 0));
+	PGX_TRY(d_nlist.alloc(2));
+	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, 2 * sizeof(uint32_t), 0));
 	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
-	hipLaunchKernelGGL(k_dust_trigger, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, d_list.data(), d_range.data(), d_nlist.data());
+	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
+			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, d_list.data(), d_range.data(),
+			   d_nlist.data());
 	PGX_HIP(hipGetLastError());
-	uint32_t n_listed = 0;
-	PGX_TRY(d_nlist.download(&n_listed, 1));
-	if (n_listed) {
-		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), d_list.data(), d_range.data(), d_nlist.data(), d_mask.data(), d_any.data());
+	uint32_t n_listed[2] = { 0, 0 };
+	PGX_TRY(d_nlist.download(n_listed, 1));
+	if (n_listed[0]) {
+		PGX_TRY(d_list2.alloc(n_listed[0]));
+		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((n_listed[0] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb,
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, d_list.data(), d_nlist.data(), d_list2.data(), d_range.data(),
+				   d_nlist.data() + 1);
+		PGX_HIP(hipGetLastError());
+		PGX_TRY(d_nlist.download(n_listed, 2));
+	}
+	if (n_listed[1]) {
+		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed[1] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
+				   rd->d_woff.data(), d_list2.data(), d_range.data(), d_nlist.data() + 1, d_mask.data(), d_any.data());
 		PGX_HIP(hipGetLastError());
 	}
 	std::vector<uint8_t> &h_any = rd->h_read_dust;
