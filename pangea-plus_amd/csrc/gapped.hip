@@ -118,12 +118,6 @@ template <int DIR> __device__ __forceinline__ int lcp(const GapSeqs &s, int qp, 
 // the first levels, one forward-only copy of the row code (left sides staged reversed), parents by one signed maximum,
 // the bound as two compares, B0 and the level count handed over by the seed stage, 4 wavefronts per SIMD: 56 ms.
 // HSPs that touch an ambiguity letter (read or database window) go to the wide kernel, which applies the flag words.
-__device__ __forceinline__ uint32_t lds_window16(const uint32_t *w, int pos)
-{
-	const int i = pos >> 4;
-	const uint64_t v = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
-	return (uint32_t)(v >> ((pos & 15) * 2));
-}
 
 // the hardware's bit scans as they are: -1 when no bit is set (the C forms add a select for that case)
 __device__ __forceinline__ uint32_t scan_low(uint32_t y)
