@@ -8,7 +8,7 @@
  * What the script computes, as its Perl actually behaves (several of its statements have no effect):
  *   - getopts('a:b:g:t:q:qc:lc:j') (trim2.4.pl:51) declares the letters a b g t q c (with a value) and l j (flags);
  *     `-qc`/`-lc` therefore never reach $QUALITY_CUTOFF / $LENGTH_CUTOFF, which stay 20 and 70 (:33-34, :94-100);
- *   - the format is the first byte of the -a file (:104-105, :117, :146): '@' FASTQ, '>' FASTA (NOT COVERED here),
+ *   - the format is the first byte of the -a file (:104-105, :117, :146): '@' FASTQ, '>' FASTA (below),
  *     otherwise QSEQ if field 7 of the first line is 1|2 and field 10 is 0|1 (:152-156);
  *   - the quality rule (:543-563, :272-287) is a running sum of (quality - cutoff) clamped at 0 from below;
  *     `end` = the first index where the sum reaches its overall maximum; the read keeps bases [0, end) — the base
@@ -18,7 +18,20 @@
  *   - FASTQ: phred+33 (:547); with -b the mates are read interleaved from the -a file (:492-495; the -b file is
  *     only opened), joined by $GAPSIZE N's (:502-505), and the second mate keeps a trailing tab (:571, :508);
  *   - QSEQ: phred+64 (:273); the first $TRUNCATE bases and qualities are cut, then $TRUNCATE-1 more bases but not
- *     qualities (:259-262); '.' becomes N (:189-190); a pair is written only if both mates survive (:199-245).
+ *     qualities (:259-262); '.' becomes N (:189-190); a pair is written only if both mates survive (:199-245);
+ *   - FASTA input (:117-143), trim2.4.pl's text (trim2.3.pl's join_fasta differs: it prints to STDOUT and tests eof
+ *     inside the loop conditions).  Without -j: needs -q; prints the -q value, then parse_fasta (:384-465) reads the
+ *     sequence file and the quality file LINE BY LINE in step.  Its cut-offs are the barewords LENGTH_CUTOFF and
+ *     QUALITY_CUTOFF (:386-387) -- strings that count as 0 -- so no record is ever rejected and the running sum is the sum
+ *     of the quality numbers themselves; `end` = last position (field index + 60 x line number) where the sum reached a
+ *     new maximum, `start` = the position of the last reset; both SURVIVE from record to record when a record never
+ *     raises the sum.  A record is printed -- to STDOUT, not to the output file -- when the NEXT header line arrives
+ *     (so the last record never is): the header up to and including its first blank ("" without one), then the stored
+ *     letters start..end, a line break after every 60th, and one more line break.  A line stores all its characters
+ *     but the last (the line break; a base if the file's last line has none).  With -j and -b: join_fasta (:301-382)
+ *     writes, per pair of records of the two files, "<header 1>_<header 2 without '>'>" and the two sequences (lines
+ *     joined) with -g N's between -- none without -g -- to the output file; the line that makes eof() true inside a
+ *     sequence loop (the last line of a file, when it is not the record's first) is never added; no closing message.
  */
 #include "o_common.h"
 #include "o_classify.h"
@@ -249,6 +262,157 @@ static void parse_qseq(reader *r1, reader *r2, long gap, long t1, long t2, obuf 
 	}
 }
 
+/* ---- FASTA input ---- */
+static int has_gt(span s) { return s.p != NULL && memchr(s.p, '>', s.n) != NULL; }
+static int at_eof(const reader *r) { return !r->p || r->pos >= r->n; }
+
+/* trim2.4.pl:384-465 */
+static void parse_fasta(reader *r1, reader *rq, obuf *out)
+{
+	int rejected = -1;
+	char *trim = NULL; /* @FinalTrim */
+	size_t n_trim = 0, cap = 0;
+	long end = 0, start = 0, first = 0, line_num = 0;
+	double max = 0, sum = 0;
+	span header = { NULL, 0 };
+	for (;;) {
+		span ls = next_line(r1);
+		if (line_is_false(ls))
+			break;
+		span lq = next_line(rq);
+		if (has_gt(ls)) {
+			/* length < "LENGTH_CUTOFF" (= 0) never holds: $Rejected only leaves -1 through the assignment below */
+			if (rejected == 0) {
+				if (header.p)
+					obuf_put(out, header.p, header.n);
+				obuf_puts(out, "\n");
+				int count_down = 60;
+				for (long a = start; a <= end; a++) {
+					count_down--;
+					if (a >= 0 && (size_t)a < n_trim)
+						obuf_put(out, trim + a, 1);
+					if (count_down == 0) {
+						obuf_puts(out, "\n");
+						count_down = 60;
+					}
+				}
+				obuf_puts(out, "\n");
+			}
+			rejected = 0;
+			const char *sp = (const char *)memchr(ls.p, ' ', ls.n);
+			header.p = ls.p;
+			header.n = sp ? (size_t)(sp - ls.p) + 1 : 0;
+			n_trim = 0;
+			max = 0;
+			sum = 0;
+			first = 0;
+			line_num = 0;
+		} else if (rejected == 0) {
+			/* every character but the last */
+			if (ls.n > 1) {
+				if (n_trim + ls.n > cap) {
+					cap = 2 * (n_trim + ls.n) + 64;
+					trim = (char *)realloc(trim, cap);
+				}
+				memcpy(trim + n_trim, ls.p, ls.n - 1);
+				n_trim += ls.n - 1;
+			}
+			/* chomp; split(/ /): leading and inner empty fields stay, trailing ones go */
+			span q = lq.p ? chomp(lq) : lq;
+			size_t nf = 0, last_nonempty = 0;
+			for (size_t i = 0, f0 = 0; q.p && i <= q.n; i++)
+				if (i == q.n || q.p[i] == ' ') {
+					nf++;
+					if (i > f0)
+						last_nonempty = nf;
+					f0 = i + 1;
+				}
+			size_t a = 0;
+			for (size_t i = 0, f0 = 0; q.p && i <= q.n && a < last_nonempty; i++)
+				if (i == q.n || q.p[i] == ' ') {
+					sum += o_perl_num(q.p + f0, i - f0); /* - "QUALITY_CUTOFF" (= 0) */
+					if (sum > max) {
+						max = sum;
+						end = (long)a + 60 * line_num;
+						start = first;
+					}
+					if (sum < 0) {
+						sum = 0;
+						first = (long)a + 60 * line_num;
+					}
+					a++;
+					f0 = i + 1;
+				}
+			line_num++;
+		}
+	}
+	free(trim);
+}
+
+/* trim2.4.pl:301-382; `gap` < 0: -g not given (or false) */
+static void join_fasta(reader *r1, reader *r2, long gap, obuf *fasta)
+{
+	int first = 1;
+	span header1 = { NULL, 0 }, header2 = { NULL, 0 };
+	obuf seq;
+	obuf_init(&seq);
+	for (;;) {
+		span l1 = next_line(r1);
+		if (line_is_false(l1))
+			break;
+		l1 = chomp(l1);
+		if (!first) {
+			span h1 = header1.p ? chomp(header1) : header1, h2 = header2.p ? chomp(header2) : header2;
+			if (h1.p)
+				obuf_put(fasta, h1.p, h1.n);
+			obuf_puts(fasta, "_");
+			for (size_t i = 0; h2.p && i < h2.n; i++)
+				if (h2.p[i] != '>')
+					obuf_put(fasta, h2.p + i, 1);
+			obuf_puts(fasta, "\n");
+		}
+		span l2;
+		if (first) {
+			l2 = next_line(r2);
+			first = 0;
+			obuf_put(fasta, l1.p, l1.n);
+			obuf_puts(fasta, "_");
+			for (size_t i = 0; l2.p && i < l2.n; i++) /* (not chomped: its line break ends the header line) */
+				if (l2.p[i] != '>')
+					obuf_put(fasta, l2.p + i, 1);
+			l1 = next_line(r1);
+		}
+		while (!has_gt(l1)) { /* grep !/>/ on an undefined line is true as well */
+			if (l1.p) {
+				span c = chomp(l1);
+				obuf_put(&seq, c.p, c.n);
+			}
+			l1 = next_line(r1);
+			if (at_eof(r1))
+				break;
+		}
+		header1 = l1;
+		for (long i = 0; i < gap; i++)
+			obuf_puts(&seq, "N");
+		l2 = next_line(r2);
+		while (!has_gt(l2)) {
+			if (l2.p) {
+				span c = chomp(l2);
+				obuf_put(&seq, c.p, c.n);
+			}
+			l2 = next_line(r2);
+			if (at_eof(r2))
+				break;
+		}
+		header2 = l2;
+		if (seq.n)
+			obuf_put(fasta, seq.p, seq.n);
+		obuf_puts(fasta, "\n");
+		seq.n = 0;
+	}
+	obuf_free(&seq);
+}
+
 static const char *const kUsage = /* :54-63 */
 	"Usage: perl trim2.pl \n"
 	"\t-a raw illumina input file read 1\n"
@@ -301,11 +465,45 @@ int o_trim2(const o_trim_opts *o, obuf *out, obuf *fasta, int *fasta_made, int *
 			t2 = (long)(t - 1.0);
 		}
 	}
-	if (rc == 0 && an > 0 && a[0] == '>')
-		rc = -1; /* parse_fasta / join_fasta: not covered */
 	*fasta_made = rc == 0;
 	reader r1 = { a, an, 0 }, r2 = { b, bn, 0 };
-	if (rc == 0 && an > 0 && a[0] == '@') {
+	if (rc == 0 && an > 0 && a[0] == '>') {
+		/* :117-143 */
+		if (o->j) {
+			if (paired) {
+				long jg = -1;
+				if (p_true(o->g)) {
+					const double g = o_perl_num(o->g, strlen(o->g));
+					jg = g > 0 ? (g > 2147483647.0 ? 2147483647L : (long)ceil(g)) : 0;
+				}
+				join_fasta(&r1, &r2, jg, fasta);
+			} else {
+				obuf_puts(out, "Error. Input is -j for joining ends, but you did not provided both sequence a and b with -a and -b options.\n\n");
+			}
+			free(a);
+			free(b);
+			return 0; /* exit: no closing message */
+		}
+		if (p_true(o->q)) {
+			obuf_printf(out, "%s\n", o->q);
+			size_t qn = 0;
+			char *q = o_read_file(o->q, &qn);
+			if (!q) {
+				obuf_printf(out, "Error: Unable to open %s required for FASTA file triming.\n", o->q);
+				free(a);
+				free(b);
+				return 0;
+			}
+			reader rq = { q, qn, 0 };
+			parse_fasta(&r1, &rq, out);
+			free(q);
+		} else {
+			obuf_puts(out, "Error: Please, specify the FASTA quality file with -q option.\n");
+			free(a);
+			free(b);
+			return 0;
+		}
+	} else if (rc == 0 && an > 0 && a[0] == '@') {
 		parse_fastq(&r1, paired, gap, out, fasta);
 	} else if (rc == 0) {
 		/* :152-156: the first line without its first byte */
