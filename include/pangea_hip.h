@@ -322,12 +322,15 @@ int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_len, int64_t
  *               every record to both), log_text alone otherwise
  *   mode        PGX_TRIM_*; for PGX_TRIM_QSEQ the script also creates <dirname of -a>/singletons/<basename>_single.txt,
  *               empty (:176-178)
- * FASTA-format input (parse_fasta / join_fasta, :301-465) returns PGX_E_FORMAT, a negative -t PGX_E_ARG. */
+ * FASTA-format input (:117-143): with `-q QUAL` parse_fasta (:384-465) -- mode PGX_TRIM_FASTA_QUAL, everything it prints
+ * is in log_text (the -q value, the records, the closing message) and fasta_text is the empty file it leaves; with `-j`
+ * and `-b` join_fasta (:301-382, trim2.4.pl's text) -- mode PGX_TRIM_FASTA_JOIN, fasta_text is the joined FASTA, no
+ * messages.  A negative -t returns PGX_E_ARG. */
 typedef struct {
 	const char *a, *b, *g, *t, *q;
 	int j;
 } pgx_trim_opts;
-enum { PGX_TRIM_NONE = 0, PGX_TRIM_FASTQ = 1, PGX_TRIM_QSEQ = 2, PGX_TRIM_UNKNOWN = 3 };
+enum { PGX_TRIM_NONE = 0, PGX_TRIM_FASTQ = 1, PGX_TRIM_QSEQ = 2, PGX_TRIM_UNKNOWN = 3, PGX_TRIM_FASTA_QUAL = 4, PGX_TRIM_FASTA_JOIN = 5 };
 int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fasta_text, size_t *fasta_len, int *mode);
 
 /* diagnostics (tools/probe_gather.py): 64-byte lines per second the device delivers to random 8-byte lane loads over a

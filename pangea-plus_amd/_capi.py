@@ -543,7 +543,7 @@ class _TrimOpts(C.Structure):
     _fields_ = [("a", C.c_char_p), ("b", C.c_char_p), ("g", C.c_char_p), ("t", C.c_char_p), ("q", C.c_char_p), ("j", C.c_int)]
 
 
-TRIM_NONE, TRIM_FASTQ, TRIM_QSEQ, TRIM_UNKNOWN = 0, 1, 2, 3
+TRIM_NONE, TRIM_FASTQ, TRIM_QSEQ, TRIM_UNKNOWN, TRIM_FASTA_QUAL, TRIM_FASTA_JOIN = 0, 1, 2, 3, 4, 5
 
 
 def trim2(a, b=None, g=None, t=None, q=None, j=False):

@@ -11,7 +11,10 @@
 // the first line, and the messages.  What the script's Perl actually computes (several statements have no
 // effect) is written out in oracle/o_trim.c's header, which the parity tests pin on the reference's own output.
 //
-// Not covered: FASTA-format input (parse_fasta / join_fasta, trim2.4.pl:301-465) and a negative -t.
+// FASTA-format input (trim2.4.pl:117-143, :301-465; the last part of this file): `-q` = parse_fasta (sequence and quality
+// files read line by line in step; the host numifies the quality fields, as it does the score columns of megaclust2; the
+// running sum, the start/end carried from record to record and the printed text are the device's), `-j -b` = join_fasta.
+// Not covered: a negative -t.
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -545,6 +548,357 @@ static int trim_qseq_device(const std::string &a, const std::string &b, uint64_t
 	return rc;
 }
 
+// ------------------------------------------------------------------------------------------------- FASTA input
+// What the two subs compute, statement by statement, is written out in oracle/o_trim.c's header (the cut-offs of parse_fasta
+// are barewords that count as 0; start / end survive from record to record; the last record is never printed; join_fasta
+// drops the line that makes eof() true inside a sequence loop).  Both are one lane per record: this is a format converter
+// for a few thousand records, not a bandwidth kernel.
+
+// flag[i] = line i holds a '>' (from line `first` on)
+__global__ void k_fa_flags(TextView t, uint64_t first, uint32_t *__restrict__ flag)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= t.n_lines)
+		return;
+	uint32_t f = 0;
+	if (i >= first) {
+		const Span l = line_of(t, i);
+		for (uint64_t k = 0; k < l.n && !f; k++)
+			f = t.text[l.off + k] == '>';
+	}
+	flag[i] = f;
+}
+
+// lines[rank[i]] = i for the flagged lines (rank = exclusive scan of the flags)
+__global__ void k_fa_scatter(const uint32_t *__restrict__ flag, const uint64_t *__restrict__ rank, uint64_t n_lines, uint64_t *__restrict__ lines)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_lines && flag[i])
+		lines[rank[i]] = i;
+}
+
+struct FaRec {
+	long long start, end; // the record's own `start` / `end` when it raised the sum (upd), later the ones in force when it is printed
+	uint64_t n_trim;      // letters @FinalTrim holds
+	uint32_t hdr_len;     // index($line, " ") + 1
+	uint32_t upd;
+};
+
+// parse_fasta, one lane per record r = header line hdr[r] and the lines up to the next header
+__global__ void k_pf_measure(TextView t, const uint64_t *__restrict__ hdr, uint64_t n_rec, const uint64_t *__restrict__ q_off, uint64_t n_qlines,
+			     const double *__restrict__ q_val, FaRec *__restrict__ rec)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_rec)
+		return;
+	const uint64_t h = hdr[r], stop = r + 1 < n_rec ? hdr[r + 1] : t.n_lines;
+	FaRec o;
+	o.start = o.end = 0;
+	o.n_trim = 0;
+	o.upd = 0;
+	const Span hl = line_of(t, h);
+	o.hdr_len = 0;
+	for (uint64_t k = 0; k < hl.n; k++)
+		if (t.text[hl.off + k] == ' ') {
+			o.hdr_len = (uint32_t)(k + 1);
+			break;
+		}
+	double max = 0, sum = 0;
+	long long first = 0, line_num = 0;
+	for (uint64_t i = h + 1; i < stop; i++) {
+		const Span l = line_of(t, i);
+		o.n_trim += l.n > 1 ? l.n - 1 : 0; // every character of the line but the last
+		if (i < n_qlines)
+			for (uint64_t a = q_off[i]; a < q_off[i + 1]; a++) {
+				sum += q_val[a]; // - "QUALITY_CUTOFF", a bareword that counts as 0 (:387)
+				const long long pos = (long long)(a - q_off[i]) + 60 * line_num;
+				if (sum > max) {
+					max = sum;
+					o.end = pos;
+					o.start = first;
+					o.upd = 1;
+				}
+				if (sum < 0) {
+					sum = 0;
+					first = pos;
+				}
+			}
+		line_num++;
+	}
+	rec[r] = o;
+}
+
+// $start / $end are not reset at a header: a record that never raised the sum is printed with the previous record's;
+// then the size of what each record prints (the last one prints nothing: its text would come with the next header)
+__global__ void k_pf_carry(FaRec *__restrict__ rec, uint64_t n_rec, uint64_t *__restrict__ out_len)
+{
+	if (blockIdx.x || threadIdx.x)
+		return;
+	long long start = 0, end = 0;
+	for (uint64_t r = 0; r < n_rec; r++) {
+		if (rec[r].upd) {
+			start = rec[r].start;
+			end = rec[r].end;
+		}
+		rec[r].start = start;
+		rec[r].end = end;
+		uint64_t len = 0;
+		if (r + 1 < n_rec) {
+			const long long last = end < (long long)rec[r].n_trim - 1 ? end : (long long)rec[r].n_trim - 1;
+			const uint64_t letters = last >= start ? (uint64_t)(last - start + 1) : 0;
+			len = rec[r].hdr_len + 1 + letters + (uint64_t)((end - start + 1) / 60) + 1;
+		}
+		out_len[r] = len;
+	}
+	out_len[n_rec] = 0;
+}
+
+__global__ void k_pf_emit(TextView t, const uint64_t *__restrict__ hdr, uint64_t n_rec, const FaRec *__restrict__ rec,
+			  const uint64_t *__restrict__ out_off, char *__restrict__ out)
+{
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r + 1 >= n_rec)
+		return;
+	const uint64_t h = hdr[r], stop = hdr[r + 1];
+	const FaRec o = rec[r];
+	char *w = out + out_off[r];
+	const Span hl = line_of(t, h);
+	for (uint32_t k = 0; k < o.hdr_len; k++)
+		*w++ = (char)t.text[hl.off + k];
+	*w++ = '\n';
+	// letters start .. end of the record's stored letters, a line break after every 60th step (a step past the stored
+	// letters prints nothing but still counts)
+	uint64_t line = h + 1, base = 0; // `base` = index of the first stored letter of `line`
+	Span l = line_of(t, line);
+	int count_down = 60;
+	for (long long a = o.start; a <= o.end; a++) {
+		count_down--;
+		if ((uint64_t)a < o.n_trim) {
+			while (line < stop && (uint64_t)a >= base + (l.n > 1 ? l.n - 1 : 0)) {
+				base += l.n > 1 ? l.n - 1 : 0;
+				line++;
+				l = line_of(t, line);
+			}
+			*w++ = (char)t.text[l.off + ((uint64_t)a - base)];
+		}
+		if (count_down == 0) {
+			*w++ = '\n';
+			count_down = 60;
+		}
+	}
+	*w++ = '\n';
+}
+
+// join_fasta: the lines one iteration of the script's loop takes from one file.  `term` = the lines >= 1 that hold a '>'
+// (n_term of them); iteration k scans from the line after terminator k - 1 (line 1 for k = 0) to terminator k; without
+// one it takes the rest of the file, except the last line when that is not the first it takes (eof() ends the loop
+// before that line is added) -- that line is then what the next header would be made of.
+struct JfSeg {
+	uint64_t first, stop;  // lines [first, stop) are joined
+	long long header_line; // the line the NEXT iteration prints as this file's header, or -1 (undefined)
+};
+__device__ JfSeg jf_segment(const uint64_t *__restrict__ term, uint64_t n_term, uint64_t n_lines, uint64_t k)
+{
+	JfSeg g;
+	const uint64_t s = k == 0 ? 1 : (k - 1 < n_term ? term[k - 1] + 1 : n_lines);
+	g.first = g.stop = s < n_lines ? s : n_lines;
+	g.header_line = -1;
+	if (s >= n_lines)
+		return g;
+	if (k < n_term) {
+		g.stop = term[k];
+		g.header_line = (long long)term[k];
+	} else if (n_lines - 1 > s) {
+		g.stop = n_lines - 1;
+		g.header_line = (long long)(n_lines - 1);
+	} else {
+		g.stop = n_lines;
+	}
+	return g;
+}
+
+__device__ __forceinline__ uint64_t chomped_len(const TextView &t, uint64_t i)
+{
+	const Span l = line_of(t, i);
+	return l.n && t.text[l.off + l.n - 1] == '\n' ? l.n - 1 : l.n;
+}
+
+// EMIT = false: the size of iteration k's output; true: its text at out_off[k]
+template <bool EMIT>
+__global__ void k_jf(TextView a, TextView b, const uint64_t *__restrict__ term_a, uint64_t n_term_a, const uint64_t *__restrict__ term_b,
+		     uint64_t n_term_b, uint64_t n_iter, long long gap, uint64_t *__restrict__ out_len, const uint64_t *__restrict__ out_off,
+		     char *__restrict__ out)
+{
+	const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_iter)
+		return;
+	uint64_t n = 0;
+	char *w = EMIT ? out + out_off[k] : nullptr;
+	auto put_line = [&](const TextView &t, long long i, bool chomp, bool drop_gt) {
+		if (i < 0 || (uint64_t)i >= t.n_lines)
+			return;
+		const Span l = line_of(t, (uint64_t)i);
+		const uint64_t len = chomp ? chomped_len(t, (uint64_t)i) : l.n;
+		for (uint64_t c = 0; c < len; c++) {
+			const char ch = (char)t.text[l.off + c];
+			if (drop_gt && ch == '>')
+				continue;
+			if (EMIT)
+				*w++ = ch;
+			n++;
+		}
+	};
+	auto put_char = [&](char ch) {
+		if (EMIT)
+			*w++ = ch;
+		n++;
+	};
+	// the header line: first iteration = line 0 of both files, the second one's not chomped; later = the lines that ended
+	// the previous iteration's sequence loops, chomped, and a line break
+	if (k == 0) {
+		put_line(a, 0, true, false);
+		put_char('_');
+		put_line(b, 0, false, true);
+	} else {
+		put_line(a, jf_segment(term_a, n_term_a, a.n_lines, k - 1).header_line, true, false);
+		put_char('_');
+		put_line(b, jf_segment(term_b, n_term_b, b.n_lines, k - 1).header_line, true, true);
+		put_char('\n');
+	}
+	const JfSeg sa = jf_segment(term_a, n_term_a, a.n_lines, k), sb = jf_segment(term_b, n_term_b, b.n_lines, k);
+	for (uint64_t i = sa.first; i < sa.stop; i++)
+		put_line(a, (long long)i, true, false);
+	for (long long g = 0; g < gap; g++)
+		put_char('N');
+	for (uint64_t i = sb.first; i < sb.stop; i++)
+		put_line(b, (long long)i, true, false);
+	put_char('\n');
+	if (!EMIT)
+		out_len[k] = n;
+}
+
+// the lines of `d` that hold a '>' from line `first` on, in order
+static int flagged_lines(const DeviceText &d, uint64_t first, DevBuf<uint64_t> &lines, uint64_t *count)
+{
+	*count = 0;
+	if (d.n_lines == 0)
+		return 0;
+	DevBuf<uint32_t> flag;
+	DevBuf<uint64_t> rank;
+	PGX_TRY(flag.alloc(d.n_lines + 1, 0, 0, true));
+	PGX_TRY(rank.alloc(d.n_lines + 1));
+	hipLaunchKernelGGL(k_fa_flags, dim3((unsigned)((d.n_lines + 255) / 256)), dim3(256), 0, 0, d.view(), first, flag.data());
+	PGX_HIP(hipGetLastError());
+	PGX_TRY((exclusive_sum<uint32_t, uint64_t>(flag.data(), rank.data(), (size_t)d.n_lines + 1)));
+	PGX_TRY(rank.download(count, 1, d.n_lines));
+	PGX_TRY(lines.alloc(*count + 1));
+	hipLaunchKernelGGL(k_fa_scatter, dim3((unsigned)((d.n_lines + 255) / 256)), dim3(256), 0, 0, flag.data(), rank.data(), d.n_lines, lines.data());
+	PGX_HIP(hipGetLastError());
+	return 0;
+}
+
+// parse_fasta (:384-465): what it prints, appended to `log`
+static int parse_fasta_device(const std::string &a, const std::string &q, Text &log)
+{
+	DeviceText da;
+	PGX_TRY(upload_lines(a, da));
+	DevBuf<uint64_t> hdr;
+	uint64_t n_rec = 0;
+	PGX_TRY(flagged_lines(da, 0, hdr, &n_rec));
+	if (n_rec < 2)
+		return 0; // a record is printed when the next header arrives
+	// the quality file, line by line: chomp, split(/ /) (leading and inner empty fields stay, trailing ones go), numified
+	std::vector<uint64_t> q_off(1, 0);
+	std::vector<double> q_val;
+	for (size_t s0 = 0; s0 < q.size();) {
+		const char *nl = (const char *)memchr(q.data() + s0, '\n', q.size() - s0);
+		const size_t e = nl ? (size_t)(nl - q.data()) : q.size();
+		size_t n_keep = 0, nf = 0;
+		for (size_t i = s0, f0 = s0; i <= e; i++)
+			if (i == e || q[i] == ' ') {
+				nf++;
+				if (i > f0)
+					n_keep = nf;
+				f0 = i + 1;
+			}
+		nf = 0;
+		for (size_t i = s0, f0 = s0; i <= e && nf < n_keep; i++)
+			if (i == e || q[i] == ' ') {
+				q_val.push_back(perl_num(q.data() + f0, i - f0));
+				nf++;
+				f0 = i + 1;
+			}
+		q_off.push_back(q_val.size());
+		s0 = e + 1;
+	}
+	DevBuf<uint64_t> d_qoff;
+	DevBuf<double> d_qval;
+	PGX_TRY(d_qoff.alloc(q_off.size()));
+	PGX_TRY(d_qoff.upload(q_off.data(), q_off.size()));
+	PGX_TRY(d_qval.alloc(q_val.size() ? q_val.size() : 1));
+	PGX_TRY(d_qval.upload(q_val.data(), q_val.size()));
+	DevBuf<FaRec> rec;
+	DevBuf<uint64_t> out_len, out_off;
+	PGX_TRY(rec.alloc(n_rec));
+	PGX_TRY(out_len.alloc(n_rec + 1));
+	PGX_TRY(out_off.alloc(n_rec + 1));
+	hipLaunchKernelGGL(k_pf_measure, dim3((unsigned)((n_rec + 127) / 128)), dim3(128), 0, 0, da.view(), hdr.data(), n_rec, d_qoff.data(),
+			   (uint64_t)(q_off.size() - 1), d_qval.data(), rec.data());
+	hipLaunchKernelGGL(k_pf_carry, dim3(1), dim3(1), 0, 0, rec.data(), n_rec, out_len.data());
+	PGX_HIP(hipGetLastError());
+	PGX_TRY((exclusive_sum<uint64_t, uint64_t>(out_len.data(), out_off.data(), (size_t)n_rec + 1)));
+	uint64_t total = 0;
+	PGX_TRY(out_off.download(&total, 1, n_rec));
+	DevBuf<char> out;
+	PGX_TRY(out.alloc(total ? total : 1));
+	hipLaunchKernelGGL(k_pf_emit, dim3((unsigned)((n_rec + 127) / 128)), dim3(128), 0, 0, da.view(), hdr.data(), n_rec, rec.data(), out_off.data(),
+			   out.data());
+	PGX_HIP(hipGetLastError());
+	const size_t at = log.s.size();
+	log.s.resize(at + total);
+	if (total)
+		PGX_HIP(hipMemcpy(&log.s[at], out.data(), total, hipMemcpyDeviceToHost));
+	trace_point("trim fasta + qual");
+	return 0;
+}
+
+// join_fasta (:301-382): the text of the output file
+static int join_fasta_device(const std::string &a, const std::string &b, long long gap, char **text, size_t *len)
+{
+	DeviceText da, db;
+	PGX_TRY(upload_lines(a, da));
+	PGX_TRY(upload_lines(b, db));
+	DevBuf<uint64_t> ta, tb;
+	uint64_t na = 0, nb = 0;
+	PGX_TRY(flagged_lines(da, 1, ta, &na));
+	PGX_TRY(flagged_lines(db, 1, tb, &nb));
+	// the loop runs while the -a file still has a line after the last terminator
+	uint64_t last_term = 0;
+	if (na)
+		PGX_TRY(ta.download(&last_term, 1, na - 1));
+	const uint64_t n_iter = da.n_lines == 0 ? 0 : na + 1 - (na && last_term == da.n_lines - 1 ? 1 : 0);
+	DevBuf<uint64_t> out_len, out_off;
+	PGX_TRY(out_len.alloc(n_iter + 1, 0, 0, true));
+	PGX_TRY(out_off.alloc(n_iter + 1));
+	if (n_iter) {
+		hipLaunchKernelGGL(k_jf<false>, dim3((unsigned)((n_iter + 127) / 128)), dim3(128), 0, 0, da.view(), db.view(), ta.data(), na, tb.data(), nb,
+				   n_iter, gap, out_len.data(), (const uint64_t *)nullptr, (char *)nullptr);
+		PGX_HIP(hipGetLastError());
+	}
+	PGX_TRY((exclusive_sum<uint64_t, uint64_t>(out_len.data(), out_off.data(), (size_t)n_iter + 1)));
+	uint64_t total = 0;
+	PGX_TRY(out_off.download(&total, 1, n_iter));
+	DevBuf<char> out;
+	PGX_TRY(out.alloc(total ? total : 1));
+	if (n_iter) {
+		hipLaunchKernelGGL(k_jf<true>, dim3((unsigned)((n_iter + 127) / 128)), dim3(128), 0, 0, da.view(), db.view(), ta.data(), na, tb.data(), nb,
+				   n_iter, gap, out_len.data(), out_off.data(), out.data());
+		PGX_HIP(hipGetLastError());
+	}
+	trace_point("trim join fasta");
+	return take_output(out, total, text, len);
+}
+
 static const char *const kTrimUsage = // trim2.4.pl:54-63
 	"Usage: perl trim2.pl \n"
 	"\t-a raw illumina input file read 1\n"
@@ -624,10 +978,43 @@ extern "C" int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fas
 		t1 = (long long)t;
 		t2 = (long long)(t - 1.0);
 	}
-	if (!a.empty() && a[0] == '>')
-		return finish(fail(PGX_E_FORMAT, "%s is FASTA: only FASTQ and QSEQ input is covered (trim2.4.pl parse_fasta / join_fasta are not)", o->a));
 	int rc = 0;
 	g_clock.tick("read files");
+	if (!a.empty() && a[0] == '>') { // :117-143; RUNBLAST was opened before (:115) and stays empty unless -j writes to it
+		if (o->j) {
+			if (paired) {
+				*mode = PGX_TRIM_FASTA_JOIN;
+				long long jg = -1; // `if ($parameters{g})`: without -g no N's at all, $GAPSIZE is not consulted (:338)
+				if (perl_true(o->g)) {
+					const double g = perl_num(o->g, strlen(o->g));
+					jg = g > 0 ? (g > 2147483647.0 ? 2147483647ll : (long long)std::ceil(g)) : 0;
+				}
+				return finish(join_fasta_device(a, b, jg, fasta_text, fasta_len)); // exit: no closing message (:124)
+			}
+			log.s += "Error. Input is -j for joining ends, but you did not provided both sequence a and b with -a and -b options.\n\n";
+			*mode = PGX_TRIM_UNKNOWN;
+			*fasta_text = (char *)calloc(1, 1);
+			return finish(0);
+		}
+		*mode = PGX_TRIM_UNKNOWN;
+		*fasta_text = (char *)calloc(1, 1);
+		if (!perl_true(o->q)) {
+			log.s += "Error: Please, specify the FASTA quality file with -q option.\n";
+			return finish(0);
+		}
+		log.printf("%s\n", o->q); // :129
+		const std::string q = read_text_file(o->q, &ok);
+		if (!ok) {
+			log.printf("Error: Unable to open %s required for FASTA file triming.\n", o->q);
+			return finish(0);
+		}
+		*mode = PGX_TRIM_FASTA_QUAL;
+		rc = parse_fasta_device(a, q, log);
+		if (rc < 0)
+			return finish(rc);
+		log.s += "Trimming complete.\n";
+		return finish(0);
+	}
 	if (!a.empty() && a[0] == '@') { // :146-149
 		*mode = PGX_TRIM_FASTQ;
 		rc = trim_fastq_device(a, paired, gap, fasta_text, fasta_len);

@@ -7,7 +7,7 @@ import random
 import pytest
 
 from conftest import ROOT, run_cmd
-from test_oracle_trim import run_trim_case, trim_cases
+from test_oracle_trim import run_trim_case, run_trim_fasta_case, trim_cases, trim_fasta_cases
 from trim_inputs import damaged as _messy, fastq_text, qseq_text, random_case
 
 pytestmark = pytest.mark.gpu
@@ -18,6 +18,12 @@ BIN = os.path.join(ROOT, "pangea-plus_amd", "bin")
 @pytest.mark.parametrize("name,info", trim_cases())
 def test_trim2_cli_matches_reference(name, info, tmp_path):
     run_trim_case([os.path.join(BIN, "trim2")], name, info, tmp_path)
+
+
+@pytest.mark.parametrize("name,info", trim_fasta_cases())
+def test_trim2_cli_fasta_modes_match_reference(name, info, tmp_path):
+    """FASTA-format input: `-q QUAL` (parse_fasta) and `-j -b` (join_fasta) against what trim2.4.pl printed and wrote."""
+    run_trim_fasta_case([os.path.join(BIN, "trim2")], name, info, tmp_path)
 
 
 def oracle_trim(oracle_bin, work, argv):
@@ -78,12 +84,43 @@ def test_trimmed_fasta_feeds_the_read_importer(tmp_path):
         assert (direct.get(i) == reads.get(i)).all()
 
 
-def test_fasta_input_and_negative_truncate_are_declined(tmp_path):
+def test_fasta_files_at_size_equal_oracle(oracle_bin, tmp_path):
+    """The two FASTA modes on files large enough to cross the line indexer's tiles: 30 000 records with a quality file,
+    and two files of 30 000 multi-line records joined with 25 N's."""
     import pangea_plus_amd as pg
     pg.init(0)
-    (tmp_path / "a.fa").write_bytes(b">r1\nACGT\n")
-    with pytest.raises(pg.PangeaError, match="FASTA"):
-        pg.trim2(str(tmp_path / "a.fa"))
+    rng = random.Random(31)
+    seq, qual, b = [], [], []
+    for i in range(30000):
+        n = rng.randint(20, 320)
+        s = "".join(rng.choice("ACGT") for _ in range(n))
+        qv = [rng.choice((0, 0, 3, 17, 25, 40, -4)) if i % 11 == 0 else rng.randint(2, 40) for _ in range(n)]
+        if i % 97 == 0:
+            qv = [0] * n   # never raises the sum: printed with the previous record's range
+        seq.append(">s%d len=%d\n" % (i, n) + "".join(s[k:k + 60] + "\n" for k in range(0, n, 60)))
+        qual.append(">s%d len=%d\n" % (i, n) + "".join(" ".join(str(v) for v in qv[k:k + 60]) + "\n" for k in range(0, n, 60)))
+        m = rng.randint(20, 320)
+        t = "".join(rng.choice("ACGT") for _ in range(m))
+        b.append(">s%d/2\n" % i + "".join(t[k:k + 70] + "\n" for k in range(0, m, 70)))
+    (tmp_path / "a.txt").write_text("".join(seq))
+    (tmp_path / "q.txt").write_text("".join(qual))
+    (tmp_path / "b.txt").write_text("".join(b))
+    rc, want, err = run_cmd([oracle_bin, "trim2", "-a", "a.txt", "-q", "q.txt"], cwd=tmp_path, timeout=600)
+    assert rc == 0, err
+    out, fasta, mode = pg.trim2(str(tmp_path / "a.txt"), q=str(tmp_path / "q.txt"))
+    assert mode == pg._capi.TRIM_FASTA_QUAL and fasta == b""
+    assert out.replace(str(tmp_path / "q.txt").encode(), b"q.txt", 1) == want and out.count(b"\n>s") == 29999  # all but the last record
+    rc, _, err = run_cmd([oracle_bin, "trim2", "-a", "a.txt", "-b", "b.txt", "-j", "-g", "25"], cwd=tmp_path, timeout=600)
+    assert rc == 0, err
+    want_fasta = (tmp_path / "output_files" / "trim2" / "a.txt_runblast.fasta").read_bytes()
+    out, fasta, mode = pg.trim2(str(tmp_path / "a.txt"), b=str(tmp_path / "b.txt"), g="25", j=True)
+    assert mode == pg._capi.TRIM_FASTA_JOIN and out == b""
+    assert fasta == want_fasta and fasta.count(b"N" * 25) >= 30000
+
+
+def test_negative_truncate_is_declined(tmp_path):
+    import pangea_plus_amd as pg
+    pg.init(0)
     (tmp_path / "a.fq").write_bytes(b"@r\nACGT\n+\nIIII\n")
     with pytest.raises(pg.PangeaError, match="negative"):
         pg.trim2(str(tmp_path / "a.fq"), t="-3")
