@@ -356,7 +356,7 @@ def test_ungapped_flag_gives_spec_v1(pg, workload, oracle_bin, tmp_path):
     assert _capi.blast_search(db, reads).format(db, reads) == open(workload / "oracle.tsv", "rb").read()
 
 
-@pytest.mark.parametrize("seed", [5, 6])
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_INDEL_SEEDS", "5,6").split(",")])
 def test_reads_with_insertions_and_deletions(pg, oracle_bin, tmp_path, seed):
     """Spec v2: 454 / Ion-style reads (homopolymer length errors, random indels) and 1 400-base queries with indels against
     a 16S-like family: gapopen > 0 rows, seeds on either side of a gap merged into one row (S3c), the one-wavefront-per-HSP
@@ -422,7 +422,7 @@ def test_reads_with_insertions_and_deletions(pg, oracle_bin, tmp_path, seed):
     assert _blast_text(pg, db, rd, tmp_path, "indel") == want.read_bytes()
 
 
-@pytest.mark.parametrize("seed", [8, 9])
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_DUST_SEEDS", "8,9").split(",")])
 def test_low_complexity_reads_are_masked_for_seeding(pg, oracle_bin, tmp_path, seed):
     """Spec v2, S3d (`-dust "20 64 1"`, BLAST+'s default): homopolymers, di- and tri-nucleotide repeats, AT-rich stretches
     in reads and database; seeds inside masked stretches vanish, extensions run through them; `-dust no` switches it off.
