@@ -200,6 +200,10 @@ int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64
 int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count, pgx_reads **out);
 /* the batch back as FASTA text (">name", one sequence line): the file trim2 hands to blastn (README.md:34 -> :96) */
 int pgx_reads_write_fasta(const pgx_reads *r, const char *path);
+/* Recompute the DUST window bits (spec S3d) of a resident batch; the import computed the same bits.  BLAST masks its
+ * queries inside every search (README.md:96 calls blastn with its defaults); a caller who wants that cost inside the
+ * search call rather than inside the import calls this first (bench.py: `dust_in_step`). */
+int pgx_reads_redo_dust(pgx_reads *r);
 void pgx_reads_close(pgx_reads *r);
 int64_t pgx_reads_count(const pgx_reads *r);
 /* packed bases of read i (2 bits per base, 32 per word, low bits first) for parity checks */

@@ -91,7 +91,7 @@ SYMBOLS = [
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
-    "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_write_fasta", "pgx_rdp_write_file", "pgx_reads_close", "pgx_reads_count",
+    "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_write_fasta", "pgx_reads_redo_dust", "pgx_rdp_write_file", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
@@ -122,6 +122,7 @@ def _declare(L):
     sig("pgx_reads_from_fasta_text", C.c_int, [C.c_char_p, C.c_size_t, I64, I64, V])
     sig("pgx_reads_get", C.c_int, [V, I64, V, I32, V])
     sig("pgx_reads_write_fasta", C.c_int, [V, S])
+    sig("pgx_reads_redo_dust", C.c_int, [V])
     sig("pgx_rdp_write_file", C.c_int, [V, V, V, S])
     sig("pgx_hits_copy", C.c_int, [V, V, I64])
     sig("pgx_hits_read_offsets", C.c_int, [V, V, I64])
@@ -304,6 +305,10 @@ class Reads(_Handle):
 
     def write_fasta(self, path):
         _check(lib().pgx_reads_write_fasta(self.ptr, _b(path)))
+
+    def redo_dust(self):
+        """Recompute the batch's DUST window bits (what BLAST does inside every search)."""
+        _check(lib().pgx_reads_redo_dust(self.ptr))
 
     def __len__(self):
         return lib().pgx_reads_count(self.ptr)

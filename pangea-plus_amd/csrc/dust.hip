@@ -355,3 +355,22 @@ int reads_dust(pgx_reads *rd)
 }
 
 } // namespace pgx
+
+// Recompute the DUST window bits of a resident batch (the same bits: the masks depend on the reads alone).  For callers who
+// count query masking as part of every search -- BLAST runs it per search -- and for bench.py's `dust_in_step` figure.
+extern "C" int pgx_reads_redo_dust(pgx_reads *r)
+{
+	if (!r)
+		return pgx::fail(PGX_E_ARG, "pgx_reads_redo_dust: null argument");
+	if (int rc = pgx::require_device())
+		return rc;
+	return pgx::guard("pgx_reads_redo_dust", [&]() -> int {
+		const bool had = r->has_dust;
+		if (int rc = pgx::reads_dust(r))
+			return rc;
+		if (r->has_dust != had)
+			return pgx::fail(PGX_E_NODEVICE, "pgx_reads_redo_dust: the masks of the batch changed between two passes");
+		return 0;
+	});
+}
+
