@@ -89,8 +89,8 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 	int size = 0, L = 0, rw_pairs = 0, rv_pairs = 0; // the window is the `size` triplets that end at the current one
 	// the entering and the leaving triplet come from two 64-bit registers that hold the next 32 letters each and move on
 	// by one letter per position (refilled every 16 positions); only the rare steps below go back to memory
-	uint64_t in_w = 0, out_w = 0;
-	int out_pos = -1;
+	uint64_t in_w = 0, out_w = 0, suf_w = 0;
+	int out_pos = -1, suf_pos = -1;
 	for (int b = 0; b < nt; b++) {
 		if ((b & 15) == 0)
 			in_w = window64(rw, b);
@@ -127,8 +127,17 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 		rv_pairs += ld.cv[t]++;
 		if (ld.cv[t] * 10 > 2 * kDustLevel) {
 			int s0;
-			do { // the suffix shrinks past the earliest copy of t
-				s0 = dust_tid(rw, ra, b - L + 1);
+			do { // the suffix shrinks past the earliest copy of t (its start only ever moves forward: a third such register;
+			     // with a load from memory per step here, and some lane of 64 shrinking at most positions, this loop was
+			     // most of the kernel)
+				const int sp = b - L + 1;
+				if (sp != suf_pos || (sp & 15) == 0) {
+					suf_w = window64(rw, sp);
+					suf_pos = sp;
+				}
+				s0 = (int)(suf_w & 63ull);
+				suf_w >>= 2;
+				suf_pos++;
 				rv_pairs -= --ld.cv[s0];
 				L--;
 			} while (s0 != t);
@@ -146,8 +155,15 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			for (int k = 0; k < 16; k++)
 				t32[k] = v32[k];
 			int rr = rv_pairs;
+			int q0 = -64; // the walk goes DOWN the read: 30 triplets per 64-bit window of letters, taken with a shift
+			uint64_t qw = 0;
 			for (int k = size - L - 1; k >= 0; k--) {
-				const int tt = dust_tid(rw, ra, b - size + 1 + k);
+				const int q = b - size + 1 + k;
+				if (q < q0 || q > q0 + 29) {
+					q0 = q >= 29 ? q - 29 : 0;
+					qw = window64(rw, q0);
+				}
+				const int tt = (int)((qw >> (2 * (q - q0))) & 63ull); // (inside the window every triplet is one of bases)
 				rr += ld.ct[tt]++;
 				if (rr * 10 > kDustLevel * (size - k - 1)) {
 					first = first < 0 ? b : first;
@@ -190,7 +206,6 @@ __global__ __launch_bounds__(64) void k_dust_mask(const uint64_t *__restrict__ f
 	bool marked = false;
 	// perfect intervals end at a position that passed the trigger: [b_first, b_last]; they hold at most 62 triplets
 	const int b_hi = (int)range[at].y, a_lo = (int)range[at].x - (kDustMaxT - 1) > 0 ? (int)range[at].x - (kDustMaxT - 1) : 0;
-	auto triplet = [&](int i) -> int { return dust_triplet(rw, ra, i); };
 	for (int k = 0; k < kDustMaxT + 2; k++)
 		ld.row[k] = 0u;
 	// one row, updated in place: before the step for (a, b) row[b - a] holds the best of [a + 1, b + 1] and row[b - a - 1]
@@ -200,8 +215,13 @@ __global__ __launch_bounds__(64) void k_dust_mask(const uint64_t *__restrict__ f
 			reinterpret_cast<uint32_t *>(ld.cnt)[k] = 0u;
 		uint32_t rsum = 0, left = 0u, below_prev = 0u; // below_prev = row below at index b - a - 1 (saved before it is overwritten)
 		int b = a;
+		uint64_t fw = 0; // letters from b on, one letter further per step, refilled every 16 (any one-to-one naming of the
+				 // triplets serves the counters)
 		for (; b <= b_hi && b < nt && b - a < kDustMaxT; b++) {
-			const int t = triplet(b);
+			if (b == a || ((b - a) & 15) == 0)
+				fw = window64(rw, b);
+			const int t = ra && (window64(ra, b) & 0x15ull) ? -1 : (int)(fw & 63ull);
+			fw >>= 2;
 			if (t < 0)
 				break;
 			rsum += ld.cnt[t]++;
