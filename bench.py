@@ -339,7 +339,7 @@ def main():
                 "setup_s": {"db_generate_and_index": t_index, "index_broadcast": t_bcast, "index_broadcast_bytes": bcast_bytes,
                             "index_rebuild_on_receivers": t_rebuild if world > 1 else 0.0,
                             "read_batch_import_ms": 1e3 * min(t_import),
-                            "read_batch_import_note": "per resident batch, before the timed region: synthetic letters, both strands, the DUST window bits of spec S3d (k_dust_trigger + k_dust_mask + k_dust_windows: 19 ms per 10 M reads, profiles/r02_b_kernel_stats.csv) and the search classes; the file-to-file `inclusive` line pays it inside its time",
+                            "read_batch_import_note": "per resident batch, before the timed region: synthetic letters, both strands, the DUST window bits of spec S3d (k_dust_trigger + k_dust_mask + k_dust_windows: 16 ms per 10 M reads, profiles/r02_b_kernel_stats.csv) and the search classes; the file-to-file `inclusive` line pays it inside its time",
                             "broadcast_mode": "whole index" if os.environ.get("PGX_BCAST_INDEX", "0") not in ("", "0") else "packed bases + offsets, index rebuilt per GPU"},
             }
             seed_roof = {"bound": "hbm", "kernel": "k_seed_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

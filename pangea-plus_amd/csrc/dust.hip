@@ -51,6 +51,13 @@ __device__ __forceinline__ int dust_triplet(const uint64_t *rw, const uint64_t *
 	return (int)(((w & 3ull) << 4) | (((w >> 2) & 3ull) << 2) | ((w >> 4) & 3ull));
 }
 
+// LDS written by one lane, read by another of the same wavefront (LDS operations of a wavefront complete in order)
+__device__ __forceinline__ void dust_wave_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
+
 struct TrigLane {
 	uint8_t cw[64], cv[64], ct[64];
 	uint32_t pad; // 49 words per lane: an even word stride put the 64 lanes' counters on two LDS banks (32-way conflicts)
@@ -75,11 +82,12 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 						      uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
 {
 	__shared__ TrigLane s_lane[64];
+	__shared__ uint32_t s_hist[64];
 	TrigLane &ld = s_lane[threadIdx.x];
 	const uint32_t at0 = blockIdx.x * 64u + threadIdx.x;
-	if (at0 >= (CONFIRM ? *n_in : n))
-		return;
-	const uint32_t r = CONFIRM ? in_list[at0] : at0;
+	// (every lane runs the loop: the wavefront shrinks suffixes together; a lane past the end has no read)
+	const bool has_read = at0 < (CONFIRM ? *n_in : n);
+	const uint32_t r = has_read ? (CONFIRM ? in_list[at0] : at0) : 0u;
 	const int nt = (int)len[r] - 2;
 	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
 	uint32_t *c32 = reinterpret_cast<uint32_t *>(&ld);
@@ -89,21 +97,31 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 	int size = 0, L = 0, rw_pairs = 0, rv_pairs = 0; // the window is the `size` triplets that end at the current one
 	// the entering and the leaving triplet come from two 64-bit registers that hold the next 32 letters each and move on
 	// by one letter per position (refilled every 16 positions); only the rare steps below go back to memory
-	uint64_t in_w = 0, out_w = 0, suf_w = 0;
-	int out_pos = -1, suf_pos = -1;
-	for (int b = 0; b < nt; b++) {
-		if ((b & 15) == 0)
-			in_w = window64(rw, b);
-		int t = (int)(in_w & 63ull);
-		in_w >>= 2;
-		if (ra && (window64(ra, b) & 0x15ull))
-			t = -1;
-		if (t < 0) { // a letter that is no base: no interval crosses it
-			for (int k = 0; k < 32; k++)
-				c32[k] = 0u;
-			size = L = rw_pairs = rv_pairs = 0;
-			continue;
+	uint64_t in_w = 0, out_w = 0;
+	int out_pos = -1;
+	int nt_wave = has_read ? nt : 0; // the loop is the wavefront's: lanes past their read's end idle but still help
+	for (int sh = 1; sh < 64; sh <<= 1) {
+		const int o = __shfl_xor(nt_wave, sh);
+		nt_wave = o > nt_wave ? o : nt_wave;
+	}
+	for (int b = 0; b < nt_wave; b++) {
+		int cv_now = 0; // the suffix's count of the entering triplet, after it entered
+		int t = -1;
+		const bool mine = has_read && b < nt;
+		if (mine) {
+			if ((b & 15) == 0)
+				in_w = window64(rw, b);
+			t = (int)(in_w & 63ull);
+			in_w >>= 2;
+			if (ra && (window64(ra, b) & 0x15ull))
+				t = -1;
+			if (t < 0) { // a letter that is no base: no interval crosses it
+				for (int k = 0; k < 32; k++)
+					c32[k] = 0u;
+				size = L = rw_pairs = rv_pairs = 0;
+			}
 		}
+		if (t >= 0) {
 		if (size >= kDustMaxT) {
 			// the oldest triplet leaves: position b - 62 (the window was full, so it is 62 triplets behind)
 			const int ob = b - kDustMaxT;
@@ -114,39 +132,83 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			const int s0 = (int)(out_w & 63ull);
 			out_w >>= 2;
 			out_pos++;
-			size--;
-			rw_pairs -= --ld.cw[s0];
-			if (L > size) {
-				L--;
-				rv_pairs -= --ld.cv[s0];
-			}
-		}
-		size++;
-		L++;
-		rw_pairs += ld.cw[t]++;
-		rv_pairs += ld.cv[t]++;
-		if (ld.cv[t] * 10 > 2 * kDustLevel) {
-			int s0;
-			do { // the suffix shrinks past the earliest copy of t (its start only ever moves forward: a third such register;
-			     // with a load from memory per step here, and some lane of 64 shrinking at most positions, this loop was
-			     // most of the kernel)
-				const int sp = b - L + 1;
-				if (sp != suf_pos || (sp & 15) == 0) {
-					suf_w = window64(rw, sp);
-					suf_pos = sp;
+			// the leaving and the entering triplet in one go: four counters read together, then written (four dependent
+			// read-modify-writes of LDS bytes per position were the rest of this kernel's time).  Same triplet leaving and
+			// entering: the counts and both pair sums end where they were.
+			const bool in_suffix = L > size - 1;
+			if (s0 != t) {
+				const int cw_s = ld.cw[s0], cv_s = ld.cv[s0], cw_t = ld.cw[t], cv_t = ld.cv[t];
+				ld.cw[s0] = (uint8_t)(cw_s - 1);
+				rw_pairs += cw_t - (cw_s - 1);
+				ld.cw[t] = (uint8_t)(cw_t + 1);
+				if (in_suffix) {
+					ld.cv[s0] = (uint8_t)(cv_s - 1);
+					rv_pairs -= cv_s - 1;
 				}
-				s0 = (int)(suf_w & 63ull);
-				suf_w >>= 2;
-				suf_pos++;
-				rv_pairs -= --ld.cv[s0];
-				L--;
-			} while (s0 != t);
+				rv_pairs += cv_t;
+				cv_now = cv_t + 1;
+				ld.cv[t] = (uint8_t)cv_now;
+			} else if (in_suffix) {
+				cv_now = ld.cv[t]; // (one out, one in)
+			} else {
+				// the leaving copy lies before the suffix: only the window's count is a wash, the suffix gains one
+				const int cv_t = ld.cv[t];
+				rv_pairs += cv_t;
+				cv_now = cv_t + 1;
+				ld.cv[t] = (uint8_t)cv_now;
+			}
+			if (!in_suffix)
+				L++; // (size stays: one left, one entered)
+		} else {
+			size++;
+			L++;
+			const int cw_t = ld.cw[t], cv_t = ld.cv[t];
+			rw_pairs += cw_t;
+			rv_pairs += cv_t;
+			ld.cw[t] = (uint8_t)(cw_t + 1);
+			cv_now = cv_t + 1;
+			ld.cv[t] = (uint8_t)cv_now;
 		}
-		if (!CONFIRM && rw_pairs * 10 > L * kDustLevel) {
+		}
+		dust_wave_sync();
+		// The suffix shrinks past the earliest copy of t when t now occurs more than 4 times in it.  Some lane of the 64 needs
+		// that at most positions, and a lane's own loop over up to 61 triplets (a counter read-modify-write each) held up
+		// the other 63: the WAVEFRONT shrinks one lane's suffix at a time -- lane j looks at the suffix's j-th triplet, a
+		// ballot finds the earliest copy, the removed triplets go into a 64-bin histogram, lane v settles triplet v's
+		// counter and its share of the pair sum (v leaves m times from a count of c: m c - m (m + 1) / 2 pairs fewer).
+		for (unsigned long long need = __ballot(cv_now * 10 > 2 * kDustLevel); need; need &= need - 1ull) {
+			const int x = __ffsll((unsigned long long)need) - 1, lane = (int)(threadIdx.x & 63);
+			const int xL = __shfl(L, x), xt = __shfl(t, x), xsp = b - xL + 1;
+			const uint64_t *xrw = reinterpret_cast<const uint64_t *>(
+				((unsigned long long)(uint32_t)__shfl((int)((uintptr_t)rw >> 32), x) << 32) | (uint32_t)__shfl((int)(uintptr_t)rw, x));
+			const int val = lane < xL ? (int)(window64(xrw, xsp + lane) & 63ull) : -1;
+			const unsigned long long hit = __ballot(val == xt);
+			const int k = __ffsll((unsigned long long)hit) - 1; // the earliest copy (the entering one is in the suffix: there is one)
+			s_hist[lane] = 0u;
+			dust_wave_sync();
+			if (lane <= k)
+				atomicAdd(&s_hist[val], 1u);
+			dust_wave_sync();
+			const int m = (int)s_hist[lane];
+			int term = 0;
+			if (m) {
+				const int c = s_lane[x].cv[lane];
+				term = m * c - m * (m + 1) / 2;
+				s_lane[x].cv[lane] = (uint8_t)(c - m);
+			}
+			for (int sh = 1; sh < 64; sh <<= 1)
+				term += __shfl_xor(term, sh);
+			if (lane == x) {
+				rv_pairs -= term;
+				L -= k + 1;
+			}
+			dust_wave_sync();
+		}
+		if (!CONFIRM && t >= 0 && rw_pairs * 10 > L * kDustLevel) {
 			first = first < 0 ? b : first;
 			last = b;
 		}
-		if (CONFIRM && rw_pairs * 10 > L * kDustLevel) {
+		if (CONFIRM && t >= 0 && rw_pairs * 10 > L * kDustLevel) {
 			// the algorithm would now look at the suffixes LONGER than that suffix, longest last; an interval that scores
 			// above the level exists in the read exactly when one of these does somewhere (its best sub-interval is
 			// perfect), so this decides whether the read has a masked base at all
