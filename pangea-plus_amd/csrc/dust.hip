@@ -8,13 +8,18 @@
 // The mask only removes SEEDS: what the seed stage reads is, per strand, one bit per read position i that says "the 28
 // bases from i on touch no masked base" (`d_dustwin_f`, `d_dustwin_r`; 64 positions per word at the read's word offset).
 //
-// k_dust_trigger  one lane per read, linear: the published algorithm's own bookkeeping (window of the last 62 triplets with
-//                 its pair count r_w; its longest suffix in which no triplet occurs more than 4 times, of L triplets)
-//                 and its test "10 r_w > 20 L", without which that algorithm never looks for a perfect interval ending
-//                 at the position.  Reads that never pass it have no masked base (93 % of random 150-base reads;
-//                 the checker's fuzz of the test against the definition: oracle/fuzz_dust.c); the others are listed
-//                 with the first and last position that passed.
-// k_dust_mask     one lane per LISTED read: the definition itself, a dynamic programme over (first triplet a descending,
+// k_dust_trigger<false>  one lane per read, linear: the published algorithm's own bookkeeping (window of the last 62
+//                 triplets with its pair count r_w; its longest suffix in which no triplet occurs more than 4 times, of L
+//                 triplets) and its test "10 r_w > 20 L", without which that algorithm never looks for a perfect interval
+//                 ending at the position.  93 % of random 150-base reads never pass it.  Triplets come from 64-bit
+//                 registers that move along the read; the suffix of ONE lane at a time is shrunk by the whole wavefront
+//                 (ballot for the earliest copy, a 64-bin histogram for the counters).
+// k_dust_trigger<true>   the listed reads again, packed: at every position that passes, the algorithm's walk over the
+//                 suffixes longer than that suffix; a read is kept when one scores above the level -- an interval above
+//                 the level exists exactly when a perfect one does (its best sub-interval), so these are the reads with a
+//                 masked base (the checker's fuzz of both tests against the definition: oracle/fuzz_dust.c) -- with the
+//                 first and last such position.
+// k_dust_mask     one lane per KEPT read: the definition itself, a dynamic programme over (first triplet a descending,
 //                 last triplet b ascending) restricted to intervals that end at or before the last such position and
 //                 start at most 61 triplets before the first; triplet counts and one row of best sub-interval scores in LDS
 // k_dust_windows  one lane per (read, 64 positions): the window bits of both strands from the mask
