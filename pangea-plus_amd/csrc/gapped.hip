@@ -430,9 +430,11 @@ template <int MAXL> struct FastLds {
 // from read_start[r] of the seed stage's main table (kFragmented: they are in the overflow table).
 // A wavefront takes the HSPs of 64 reads (at most kBlkItems at a time), orders them by the seed stage's work estimate
 // (a counting sort in LDS), and runs them 64 at a time: lanes of one round have about the same number of rows.
-template <bool FLAT, int MAXL>
-// (4 wavefronts per SIMD: 128 registers -- the row is 39 of them; the compiler parks three values in scratch around the rows)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
+template <bool FLAT, int MAXL, int WAVES>
+// (WAVES per SIMD: 4 = 128 registers -- the row is 39 of them; the compiler parks three values in scratch around the rows;
+// 5 = 96 registers, 24 values in scratch, for reads of <= 160 bases whose staged letters fit 7.5 KB of LDS: worth 6 % once
+// the grid is two full rounds of resident wavefronts -- with 8 192 blocks on 5 120 slots the second round ran at 60 %)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_fast(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
 						     const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
 						     uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
 						     unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
@@ -806,30 +808,33 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	PGX_TRY(gw.big_count.ensure(1));
 	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
 	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
-	PGX_TRY(gw.order.ensure((size_t)8192 * kBlkItems));
+	PGX_TRY(gw.order.ensure((size_t)10240 * kBlkItems));
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
 	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
-	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 32);
+	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
 	const int dbg = getenv("PGX_GAP_DBG") ? atoi(getenv("PGX_GAP_DBG")) : 0; // (measurement aid)
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy)
-#define PGX_GAPPED_LAUNCH(ML)                                                                                                                \
+#define PGX_GAPPED_LAUNCH(ML, WV)                                                                                                              \
 	do {                                                                                                                                 \
 		v.key = main_key;                                                                                                            \
-		hipLaunchKernelGGL((k_gapped_fast<false, ML>), dim3(grid ? grid : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
+		const unsigned grid_wv = std::min<unsigned>(grid, 256u * 4u * WV * 2u); /* two full rounds of resident wavefronts */  \
+		hipLaunchKernelGGL((k_gapped_fast<false, ML, WV>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
 				   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
 		v.key = ovf_key;                                                                                                             \
-		hipLaunchKernelGGL((k_gapped_fast<true, ML>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
+		hipLaunchKernelGGL((k_gapped_fast<true, ML, WV>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
 				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
 				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
 	} while (0)
-	if (max_len <= 192)
-		PGX_GAPPED_LAUNCH(192);
+	if (max_len <= 160)
+		PGX_GAPPED_LAUNCH(160, 5);
+	else if (max_len <= 192)
+		PGX_GAPPED_LAUNCH(192, 4);
 	else if (max_len <= 320)
-		PGX_GAPPED_LAUNCH(320);
+		PGX_GAPPED_LAUNCH(320, 4);
 	else
-		PGX_GAPPED_LAUNCH(512);
+		PGX_GAPPED_LAUNCH(512, 4);
 #undef PGX_GAPPED_LAUNCH
 	hipLaunchKernelGGL(k_gapped_big, dim3(256 * 8), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap);
 	PGX_HIP(hipGetLastError());
