@@ -287,8 +287,8 @@ constexpr uint32_t kFragmented = 0xFFFFFFFFu; // read_start of a read whose hits
 // gapped.hip: spec v2 S3b on the initial HSPs of a seed-stage table (main table addressed through read_start / read_cnt,
 // overflow table flat), in place; long reads and extensions with many differences go through `big` lists
 struct GappedWork {
-	DevBuf<unsigned long long> big_list;
-	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats)
+	DevBuf<unsigned long long> big_list, big_list2; // HSPs for the one-wavefront-per-HSP kernel; those of them that need its large rows
+	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats), [1] of the second list
 	DevBuf<uint2> side_main, side_ovf; // per table slot: the left side's extension, parked until the right side is done
 	DevBuf<uint32_t> order;            // per block of k_gapped_fast: the pool's HSPs in cost order
 };

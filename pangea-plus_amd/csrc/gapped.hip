@@ -653,13 +653,16 @@ namespace pgx {
 
 // ------------------------------------------------------------------------------------------ one wavefront per HSP
 // cell: x = i, y = mismatches | gap openings << 12 | kind << 24 | matched-after << 26
-constexpr int kBigCells = 2 * kGDmax + 3;
-struct BigLds {
-	uint2 row[2][kBigCells];
+// DMAX = differences per side this instance can hold: 62 (the diagonals of a level fit one wavefront, 2 KB of LDS: 32
+// wavefronts per CU) for nearly every listed HSP, kGDmax = 1 000 (32 KB: 5 per CU) for the few sides that need more --
+// with the large rows only, reads of 300-500 bases, most of whose HSPs are listed, ran at 5 wavefronts per CU
+template <int DMAX> struct BigLds {
+	uint2 row[2][2 * DMAX + 3];
 	int ring[kGLag + 1]; // best score with at most d differences, for the last kGLag + 1 values of d
 };
 
-template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int q0, int64_t d0, int M, int N, Side &out)
+// returns false when cells were still alive after DMAX < kGDmax differences (the side needs the larger instance)
+template <int DIR, int DMAX> __device__ bool greedy_big(BigLds<DMAX> *lds, const GapSeqs &s, int q0, int64_t d0, int M, int N, Side &out)
 {
 	const int lane = threadIdx.x & 63;
 	auto slide = [&](int i, int j) {
@@ -671,8 +674,8 @@ template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int
 	out.s2 = 2 * i0;
 	out.mism = out.gopen = 0;
 	if (i0 == M || i0 == N)
-		return;
-	constexpr int C = kGDmax + 1;
+		return true;
+	constexpr int C = DMAX + 1;
 	int cur_row = 0;
 	if (lane == 0) {
 		lds->row[0][C] = make_uint2((uint32_t)i0, i0 > 0 ? 1u << 26 : 0u);
@@ -680,7 +683,7 @@ template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int
 	}
 	lds_sync();
 	int best = 2 * i0, L = 0, U = 0;
-	for (int d = 1; d <= kGDmax; d++) {
+	for (int d = 1; d <= DMAX; d++) {
 		const int tcmp = d >= kGLag ? lds->ring[(d - kGLag) % (kGLag + 1)] : 0;
 		const uint2 *pa = lds->row[cur_row];
 		uint2 *pb = lds->row[cur_row ^ 1];
@@ -760,29 +763,38 @@ template <int DIR> __device__ void greedy_big(BigLds *lds, const GapSeqs &s, int
 			lds->ring[d % (kGLag + 1)] = best;
 		lds_sync();
 		if (nl > nu)
-			return;
+			return true;
 		cur_row ^= 1;
 		L = nl;
 		U = nu;
 	}
+	return DMAX == kGDmax; // (the spec's limit: what was found within 1 000 differences stands)
 }
 
+template <int DMAX>
 __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned long long *__restrict__ list, const uint32_t *__restrict__ count,
-						    uint32_t cap)
+						    uint32_t cap, unsigned long long *__restrict__ next_list, uint32_t *__restrict__ next_count)
 {
-	__shared__ BigLds lds;
+	__shared__ BigLds<DMAX> lds;
 	const uint32_t n = *count < cap ? *count : cap;
 	for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
 		pgx_hit *hp = reinterpret_cast<pgx_hit *>((uintptr_t)list[idx]);
 		const pgx_hit h = *hp;
 		const Anchor a = anchor_of(v, h);
 		Side l, r;
-		greedy_big<-1>(&lds, a.s, a.qa - 1, a.S0 + a.sa - 1, a.qa, a.sa, l);
+		const bool okl = greedy_big<-1, DMAX>(&lds, a.s, a.qa - 1, a.S0 + a.sa - 1, a.qa, a.sa, l);
 		lds_sync();
-		greedy_big<+1>(&lds, a.s, a.qa, a.S0 + a.sa, a.L - a.qa, a.slen - a.sa, r);
+		const bool okr = okl && greedy_big<+1, DMAX>(&lds, a.s, a.qa, a.S0 + a.sa, a.L - a.qa, a.slen - a.sa, r);
 		lds_sync();
-		if ((threadIdx.x & 63) == 0)
-			write_gapped(hp, h, a, l, r);
+		if ((threadIdx.x & 63) == 0) {
+			if (okl && okr) {
+				write_gapped(hp, h, a, l, r);
+			} else if (next_list) {
+				const uint32_t w = atomicAdd(next_count, 1u);
+				if (w < cap)
+					next_list[w] = list[idx];
+			}
+		}
 	}
 }
 
@@ -805,12 +817,13 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const unsigned long long want = long_reads ? hit_cap + ovf_cap : (1ull << 20);
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
-	PGX_TRY(gw.big_count.ensure(1));
+	PGX_TRY(gw.big_list2.ensure(big_cap));
+	PGX_TRY(gw.big_count.ensure(2));
 	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
 	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
 	PGX_TRY(gw.order.ensure((size_t)10240 * kBlkItems));
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
-	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, sizeof(uint32_t), stream));
+	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 2 * sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
 	const int dbg = getenv("PGX_GAP_DBG") ? atoi(getenv("PGX_GAP_DBG")) : 0; // (measurement aid)
@@ -832,11 +845,15 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	else if (max_len <= 192)
 		PGX_GAPPED_LAUNCH(192, 4);
 	else if (max_len <= 320)
-		PGX_GAPPED_LAUNCH(320, 4);
+		PGX_GAPPED_LAUNCH(320, 3);
 	else
-		PGX_GAPPED_LAUNCH(512, 4);
+		PGX_GAPPED_LAUNCH(512, 2);
 #undef PGX_GAPPED_LAUNCH
-	hipLaunchKernelGGL(k_gapped_big, dim3(256 * 8), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap);
+	// the listed HSPs: first with rows for 62 differences a side, the rest (their own, shorter list) with rows for 1 000
+	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap,
+			   gw.big_list2.data(), gw.big_count.data() + 1);
+	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, gw.big_list2.data(), gw.big_count.data() + 1, cap,
+			   (unsigned long long *)nullptr, (uint32_t *)nullptr);
 	PGX_HIP(hipGetLastError());
 	return 0;
 }
