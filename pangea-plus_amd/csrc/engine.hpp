@@ -289,7 +289,7 @@ constexpr uint32_t kFragmented = 0xFFFFFFFFu; // read_start of a read whose hits
 struct GappedWork {
 	DevBuf<unsigned long long> big_list, big_list2; // HSPs for the one-wavefront-per-HSP kernel; those of them that need its large rows
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats), [1] of the second list
-	DevBuf<uint2> side_main, side_ovf; // per table slot: the left side's extension, parked until the right side is done
+	DevBuf<uint2> side_main, side_ovf, side_list; // per table slot (per list entry, second tier): the left side's extension, parked until the right side is done
 	DevBuf<uint32_t> order;            // per block of k_gapped_fast: the pool's HSPs in cost order
 };
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,

@@ -28,14 +28,14 @@ namespace pgx {
 
 constexpr int kGX2 = 108;     // 2 X
 constexpr int kGLag = 19;     // floor((X + 1/2) / 3) + 1: the X-drop test looks at the best score 19 differences earlier
-constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel: below kGLag, so it never makes an X-drop test
+constexpr int kGFastD = 18;   // differences per side of the lane-per-HSP kernel's first tier: below kGLag, so it never makes an X-drop test
+constexpr int kGFastD2 = 40;  // second tier (the HSPs the first one lists): keeps the score history the X-drop test needs
 constexpr int kGDmax = 1000;  // differences per side, spec
-constexpr int kGFastCells = 2 * kGFastD + 3;
 constexpr int kGGroup = 4;    // diagonals per group of the unrolled row (lane kernel)
 constexpr int kGUnrollLevels = 7; // levels of the lane kernel compiled as straight code
 constexpr uint32_t kCellNone = 0x80000000u; // lane kernel: a dead cell holds i = -32768
 constexpr uint32_t kBigNone = 0xFFFFFFFFu;  // wide kernel: a dead cell
-static_assert(kGFastD < kGLag, "the lane-per-HSP kernel keeps no score history");
+static_assert(kGFastD < kGLag, "the first tier keeps no score history");
 
 #ifdef PGX_STAGE_PROBES
 // measurement builds: [0] cell steps of a wavefront, [1] cells evaluated by lanes, [2] slide rounds (wavefront) inside cell
@@ -213,7 +213,7 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // lives in REGISTERS (kGFastCells words, indexed by the unrolled k) and is updated in place, k ascending.  Lanes whose
 // cell is dead, or that have finished, idle for that step; the caller groups sides of similar cost to keep that rare.
 // cell: bits 16-31 i (signed; kCellNone holds -32768 there, so a dead parent loses every maximum), 14-15 zero (the
-// parents' priority goes there while they are compared), 7-11 mismatches, 2-6 gap openings, 0-1 the OPEN gap: the kind of
+// parents' priority goes there while they are compared), 8-13 mismatches, 2-7 gap openings, 0-1 the OPEN gap: the kind of
 // the path's last column (1 gap in the subject row, 2 gap in the query row) if that column is a gap and no letter matched
 // after it, else 0 -- a gap column opens a gap unless it continues that one.  With i on top, ONE signed maximum over the
 // three parent words (each moved to the row it would reach, its priority in bits 14-15) yields the furthest row, the
@@ -228,7 +228,10 @@ __device__ __forceinline__ void write_gapped(pgx_hit *hp, const pgx_hit &h, cons
 // neither reach the final best nor tie it, its children's bounds are lower still, and no surviving cell has such a
 // parent.  A side that is still alive at d = kGLag goes to the wide kernel, which makes the X-drop tests.
 // Returns false for a lane whose cells are still alive after kGFastD differences.
-__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, bool on, int q0, int d0, int M, int N, int b0, Side &out)
+// D = differences per side this instance holds; `xring` (D >= kGLag only) = this lane's T[0 .. D - kGLag] in LDS: the best
+// score seen with at most d' differences, for the X-drop test of level d' + kGLag
+template <int D>
+__device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t *dbwin, int *xring, bool on, int q0, int d0, int M, int N, int b0, Side &out)
 {
 	int slide_rounds = 0;
 	(void)slide_rounds;
@@ -257,11 +260,15 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	out.i = out.j = i0;
 	out.s2 = 2 * i0;
 	bool live = on && !(i0 == M || i0 == N); // this lane still has cells to explore
-	uint32_t R[kGFastCells];
+	constexpr int kCells = 2 * D + 3;
+	uint32_t R[kCells];
 #pragma unroll
-	for (int c = 0; c < kGFastCells; c++)
+	for (int c = 0; c < kCells; c++)
 		R[c] = kCellNone;
-	constexpr int C = kGFastD + 1;
+	constexpr int C = D + 1;
+	int tbest = 2 * i0, tcmp = -(1 << 29); // the true best so far (the X-drop history; `best` below may start above it)
+	if constexpr (D >= kGLag)
+		xring[0] = tbest;
 	R[C] = live ? (uint32_t)i0 << 16 : kCellNone;
 	// `best` starts one below B0 when the anchor's diagonal does better than its first run: no cell below B0 can be the
 	// answer (the diagonal's own cells reach B0), so the bound test needs one number, not two
@@ -308,7 +315,9 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 		const int jj0 = v - k;
 		// (a lane that is not live holds a row of dead cells -- every cell of its last level was written dead -- so it
 		// needs no test of its own: v is -32768 there)
-		const bool alive = ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & can;
+		bool alive = ((uint32_t)v <= (uint32_t)M) & ((uint32_t)jj0 <= (uint32_t)N) & can;
+		if constexpr (D >= kGLag)
+			alive = alive & (v + jj0 - six_d >= tcmp); // the X-drop test on the score before sliding (tcmp = T[d - 19] - 2 X)
 		uint32_t nc = kCellNone;
 		GAP_STAT(0, 1);
 		GAP_STAT(1, __popcll(__ballot(alive)));
@@ -328,9 +337,11 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 			}
 			// one more mismatch, or one more gap opening unless the column continues the parent's open gap
 			const uint32_t pst = (uint32_t)m3;
-			const uint32_t inc = kind == 0u ? 1u << 7 : ((pst & 3u) != kind ? 1u << 2 : 0u);
-			nc = ((uint32_t)ii << 16) | (((pst & 0xFFCu) + inc) | (ii > v ? 0u : kind));
+			const uint32_t inc = kind == 0u ? 1u << 8 : ((pst & 3u) != kind ? 1u << 2 : 0u);
+			nc = ((uint32_t)ii << 16) | (((pst & 0x3FFCu) + inc) | (ii > v ? 0u : kind));
 			const int s2 = ii + jj - six_d;
+			if constexpr (D >= kGLag)
+				tbest = s2 > tbest ? s2 : tbest;
 			if (s2 > best) {
 				best = s2;
 				best_cell = nc;
@@ -377,47 +388,56 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 				GAP_STAT(7, __popcll(__ballot(live)));
 				static_for<C - d, C + d + 1>([&](auto cc) { cell(cc, 6 * d, std::integral_constant<int, d - 1>{}); });
 				live = any && more(d);
+				if constexpr (D >= kGLag)
+					xring[d] = tbest; // (d <= kGUnrollLevels <= D - kGLag)
 			}
 		}
 	});
 	for (int d = kGUnrollLevels + 1; !done && __ballot(live) != 0ull; d++) {
-		if (d > kGFastD) {
+		if (d > D) {
 			over = live;
 			break;
 		}
+		if constexpr (D >= kGLag)
+			tcmp = d >= kGLag ? xring[d - kGLag] - kGX2 : -(1 << 29);
 		prev = kCellNone;
 		any = false;
 		GAP_STAT(3, 1);
 		GAP_STAT(7, __popcll(__ballot(live)));
 		const int six_d = 6 * d;
-		static_for<0, (kGFastCells - 2 + kGGroup - 1) / kGGroup>([&](auto gc) {
+		static_for<0, (kCells - 2 + kGGroup - 1) / kGGroup>([&](auto gc) {
 			constexpr int c0 = 1 + decltype(gc)::value * kGGroup;
 			if (!(c0 + kGGroup - 1 - C < -d || c0 - C > d)) {
-				static_for<c0, (c0 + kGGroup < kGFastCells - 1 ? c0 + kGGroup : kGFastCells - 1)>([&](auto cc) {
+				static_for<c0, (c0 + kGGroup < kCells - 1 ? c0 + kGGroup : kCells - 1)>([&](auto cc) {
 					constexpr int k = decltype(cc)::value - C;
 					if (!(k < -d || k > d))
-						cell(cc, six_d, std::integral_constant<int, kGFastD>{});
+						cell(cc, six_d, std::integral_constant<int, D>{});
 				});
 			}
 		});
 		live = any && more(d);
+		if constexpr (D >= kGLag)
+			if (d <= D - kGLag)
+				xring[d] = tbest;
 	}
 	out.i = (int)best_cell >> 16;
 	out.j = out.i - best_k;
 	out.s2 = best > 2 * i0 ? best : 2 * i0; // (no cell passed the first run: B0 was that run)
-	out.mism = (int)((best_cell >> 7) & 31u);
-	out.gopen = (int)((best_cell >> 2) & 31u);
+	out.mism = (int)((best_cell >> 8) & 63u);
+	out.gopen = (int)((best_cell >> 2) & 63u);
 	return !over;
 }
 
 constexpr int kBlkItems = 2048; // HSPs a wavefront orders at a time
 constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of the seed run, capped at 15
 
-template <int MAXL> struct FastLds {
-	static constexpr int kRd = MAXL / 16 + 2;                          // read strand, 16 bases per word
-	static constexpr int kDb = (MAXL + 2 * kGFastD + 48 + 15) / 16 + 1; // database window
+template <int MAXL, int D> struct FastLds {
+	static constexpr int kRd = MAXL / 16 + 2;                    // read strand, 16 bases per word
+	static constexpr int kDb = (MAXL + 2 * D + 48 + 15) / 16 + 1; // database window
 	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
+	static constexpr int kRing = D >= kGLag ? ((D - kGLag + 2) | 1) : 1; // the X-drop history of a lane (second tier)
 	uint32_t seq[64][kSeq];
+	int xring[D >= kGLag ? 64 : 0][kRing]; // (nothing in the first tier: 256 bytes more there cost a fifth wavefront its LDS)
 	uint32_t bucket[kKeyBuckets];
 	// (the pool's HSPs in cost order live in GLOBAL scratch, one array per block: with them here the kernel held 12.6 KB of
 	// LDS per wavefront = 3 wavefronts per SIMD; without, 8.5 KB = 4, and a wavefront of this kernel is bound by its own
@@ -430,7 +450,10 @@ template <int MAXL> struct FastLds {
 // from read_start[r] of the seed stage's main table (kFragmented: they are in the overflow table).
 // A wavefront takes the HSPs of 64 reads (at most kBlkItems at a time), orders them by the seed stage's work estimate
 // (a counting sort in LDS), and runs them 64 at a time: lanes of one round have about the same number of rows.
-template <bool FLAT, int MAXL, int WAVES>
+// MODE 0: the reads' pools of the main table; 1 (FLAT): the overflow table; 2 (LIST): the HSPs the first tier listed, as
+// pointers to their seed records (`table` = the list as pgx_hit **; a side's result is parked by list position).
+// D: differences per side (18 first tier, 40 second tier, which makes the X-drop tests).
+template <int MODE, int MAXL, int WAVES, int D>
 // (WAVES per SIMD: 4 = 128 registers -- the row is 39 of them; the compiler parks three values in scratch around the rows;
 // 5 = 96 registers, 24 values in scratch, for reads of <= 160 bases whose staged letters fit 7.5 KB of LDS: worth 6 % once
 // the grid is two full rounds of resident wavefronts -- with 8 192 blocks on 5 120 slots the second round ran at 60 %)
@@ -440,19 +463,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 						     unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
 						     uint2 *__restrict__ side_res, int dbg, uint32_t *__restrict__ order_all)
 {
-	using Lds = FastLds<MAXL>;
+	constexpr bool FLAT = MODE != 0, LIST = MODE == 2;
+	using Lds = FastLds<MAXL, D>;
 	__shared__ Lds lds;
 	uint32_t *order = order_all + (size_t)blockIdx.x * kBlkItems; // written and read by this wavefront only, through L2
 	const int lane = threadIdx.x & 63;
 	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
-	const unsigned long long n_flat = FLAT ? (*flat_count < table_cap ? *flat_count : table_cap) : 0ull;
-	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
+	const unsigned long long n_flat_raw = FLAT ? (LIST ? (unsigned long long)*reinterpret_cast<const uint32_t *>(flat_count) : *flat_count) : 0ull;
+	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
+	// (the second tier's list has no order to exploit: 64 entries, one round a side, per block -- with 2 048 the few listed
+	// HSPs of a short-read batch all fell to one or two wavefronts)
+	constexpr unsigned long long kItems = LIST ? 64ull : (unsigned long long)kBlkItems;
+	const unsigned long long n_blocks = FLAT ? (n_flat + kItems - 1) / kItems : ((unsigned long long)n_reads + 63ull) / 64ull;
 
 	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
 		uint32_t excl = 0, st = 0, T;
 		if (FLAT) {
-			const unsigned long long left = n_flat - blk * kBlkItems;
-			T = (uint32_t)(left < (unsigned long long)kBlkItems ? left : (unsigned long long)kBlkItems);
+			const unsigned long long left = n_flat - blk * kItems;
+			T = (uint32_t)(left < kItems ? left : kItems);
 		} else {
 			const uint32_t r = (uint32_t)blk * 64u + lane;
 			uint32_t cnt = 0;
@@ -472,10 +500,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 			excl = incl - cnt;
 			T = __shfl(incl, 63);
 		}
+		// the bucket of an HSP's side: the seed stage's level estimate (first tier: the key byte of its slot; second tier:
+		// the record's own columns, whose estimates are not cut at 15, moved down so that 16 .. 31 spread over the buckets)
+		auto key_of = [&](const pgx_hit *p, int side) -> uint32_t {
+			if (LIST) // (the record's estimates are cut at 15, which is where this tier's sides begin: no order to be had)
+				return (uint32_t)(side ? p->gapopen : p->mismatch) & 15u;
+			return (uint32_t)(v.key[p - table] >> (4 * side)) & 15u;
+		};
 		// item -> its record
 		auto locate = [&](uint32_t item) -> pgx_hit * {
+			if (LIST)
+				return reinterpret_cast<pgx_hit *const *>(table)[blk * kItems + item];
 			if (FLAT)
-				return table + blk * kBlkItems + item;
+				return table + blk * kItems + item;
 			int o = 0;
 #pragma unroll
 			for (int step = 32; step >= 1; step >>= 1) {
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 					const uint32_t item = it + lane;
 					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
 					if (item < n_it)
-						atomicAdd(&lds.bucket[(v.key[p - table] >> (4 * side)) & 15u], 1u);
+						atomicAdd(&lds.bucket[key_of(p, side)], 1u);
 				}
 				lds_sync();
 				{
@@ -521,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 					const uint32_t item = it + lane;
 					const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
 					if (item < n_it) {
-						const uint32_t slot = atomicAdd(&lds.bucket[(v.key[p - table] >> (4 * side)) & 15u], 1u);
+						const uint32_t slot = atomicAdd(&lds.bucket[key_of(p, side)], 1u);
 						__hip_atomic_store(&order[slot], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
 				}
@@ -532,7 +569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 					const bool mine = it + lane < n_it;
 					const uint32_t item = __hip_atomic_load(&order[mine ? it + lane : n_it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					pgx_hit *hp = locate(chunk + item);
-					const size_t slot = (size_t)(hp - table);
+					const size_t slot = LIST ? (size_t)(blk * kItems + chunk + item) : (size_t)(hp - table);
 					pgx_hit h;
 					h.read = h.subject = h.qstart = h.qend = h.sstart = h.send = h.score = 0;
 					h.mismatch = h.gapopen = 0;
@@ -547,9 +584,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 					if (mine) {
 						h = *hp;
 						a = anchor_of(v, h);
-						// the database window of this HSP: from kGFastD + 16 bases left of where the read's first base
+						// the database window of this HSP: from D + 16 bases left of where the read's first base
 						// would lie, in whole 16-base words
-						const int64_t lo = ((int64_t)a.gpos - a.qa - kGFastD - 16) >> 4; // word index (may be negative: front padding)
+						const int64_t lo = ((int64_t)a.gpos - a.qa - D - 16) >> 4; // word index (may be negative: front padding)
 						bool wide = a.L > MAXL;
 						if (side == 1) {
 							parked = side_res[slot];
@@ -609,19 +646,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 						lds_sync();
 						continue; // (probe: ordering + staging only)
 					}
-					ok = greedy_rows(rdw, dbwin, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd);
+					ok = greedy_rows<D>(rdw, dbwin, D >= kGLag ? &lds.xring[D >= kGLag ? lane : 0][0] : nullptr, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd);
 					if (mine) {
 						if (side == 0) {
-							// parked: i | j << 10 | mismatches << 20 | gap openings << 25 ; gap columns | wide << 31
+							// parked: i | j << 10 | mismatches << 20 | gap openings << 26 ; gap columns | wide << 31
 							const uint32_t gaps = (uint32_t)((sd.i + sd.j - sd.s2) / 6 - sd.mism);
-							side_res[slot] = (on && ok) ? make_uint2((uint32_t)sd.i | ((uint32_t)sd.j << 10) | ((uint32_t)sd.mism << 20) | ((uint32_t)sd.gopen << 25), gaps)
+							side_res[slot] = (on && ok) ? make_uint2((uint32_t)sd.i | ((uint32_t)sd.j << 10) | ((uint32_t)sd.mism << 20) | ((uint32_t)sd.gopen << 26), gaps)
 										    : make_uint2(0u, 1u << 31);
 						} else if (on && ok) {
 							Side l;
 							l.i = (int)(parked.x & 1023u);
 							l.j = (int)((parked.x >> 10) & 1023u);
-							l.mism = (int)((parked.x >> 20) & 31u);
-							l.gopen = (int)(parked.x >> 25);
+							l.mism = (int)((parked.x >> 20) & 63u);
+							l.gopen = (int)(parked.x >> 26);
 							l.s2 = l.i + l.j - 6 * (l.mism + (int)parked.y);
 							write_gapped(hp, h, a, l, sd);
 						} else {
@@ -656,17 +693,57 @@ namespace pgx {
 // DMAX = differences per side this instance can hold: 62 (the diagonals of a level fit one wavefront, 2 KB of LDS: 32
 // wavefronts per CU) for nearly every listed HSP, kGDmax = 1 000 (32 KB: 5 per CU) for the few sides that need more --
 // with the large rows only, reads of 300-500 bases, most of whose HSPs are listed, ran at 5 wavefronts per CU
+constexpr int kBigStageL = 2048; // reads up to this length have their letters staged in LDS by the small tier
 template <int DMAX> struct BigLds {
 	uint2 row[2][2 * DMAX + 3];
 	int ring[kGLag + 1]; // best score with at most d differences, for the last kGLag + 1 values of d
+	// the small tier's staged letters (16 per word): the read strand, and the database window from DMAX + 16 bases left of
+	// where the read's first base would lie
+	static constexpr int kRd = DMAX < kGDmax ? kBigStageL / 16 + 2 : 1, kDb = DMAX < kGDmax ? (kBigStageL + 2 * DMAX + 48 + 15) / 16 + 2 : 1;
+	uint32_t rd[kRd], db[kDb];
 };
 
+// lcp<DIR> on letters staged in LDS (no ambiguity flags: HSPs that touch one read the sequences in memory)
+__device__ __forceinline__ uint32_t window16_lds(const uint32_t *w, int pos)
+{
+	const int i = pos >> 4;
+	const uint64_t v = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+	return (uint32_t)(v >> ((pos & 15) * 2));
+}
+template <int DIR> __device__ __forceinline__ int lcp_lds(const uint32_t *rd, const uint32_t *db, int qp, int dp, int cap)
+{
+	int n = 0;
+	while (n < cap) {
+		const int take = cap - n < 16 ? cap - n : 16;
+		const int q0 = DIR > 0 ? qp + n : qp - n - (take - 1), d0 = DIR > 0 ? dp + n : dp - n - (take - 1);
+		const uint32_t x = window16_lds(rd, q0) ^ window16_lds(db, d0);
+		uint32_t y = (x | (x >> 1)) & 0x55555555u;
+		if (take < 16)
+			y &= (1u << (2 * take)) - 1u;
+		int run;
+		if (DIR > 0) {
+			run = y ? (__ffs((int)y) - 1) >> 1 : take;
+		} else {
+			y <<= 2 * (16 - take);
+			run = y ? __clz((int)y) >> 1 : take;
+		}
+		n += run;
+		if (run < take)
+			break;
+	}
+	return n;
+}
+
 // returns false when cells were still alive after DMAX < kGDmax differences (the side needs the larger instance)
-template <int DIR, int DMAX> __device__ bool greedy_big(BigLds<DMAX> *lds, const GapSeqs &s, int q0, int64_t d0, int M, int N, Side &out)
+// staged: the letters are in lds->rd / lds->db and `dwin` is d0's position in that window
+template <int DIR, int DMAX>
+__device__ bool greedy_big(BigLds<DMAX> *lds, const GapSeqs &s, bool staged, int q0, int64_t d0, int dwin, int M, int N, Side &out)
 {
 	const int lane = threadIdx.x & 63;
 	auto slide = [&](int i, int j) {
 		const int cap = M - i < N - j ? M - i : N - j;
+		if (DMAX < kGDmax && staged)
+			return lcp_lds<DIR>(lds->rd, lds->db, q0 + DIR * i, dwin + DIR * j, cap);
 		return lcp<DIR>(s, q0 + DIR * i, d0 + DIR * j, cap);
 	};
 	const int i0 = slide(0, 0);
@@ -782,9 +859,40 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 		const pgx_hit h = *hp;
 		const Anchor a = anchor_of(v, h);
 		Side l, r;
-		const bool okl = greedy_big<-1, DMAX>(&lds, a.s, a.qa - 1, a.S0 + a.sa - 1, a.qa, a.sa, l);
+		bool staged = false;
+		int awin = 0;
+		if (DMAX < kGDmax && a.L <= kBigStageL) {
+			// letters into LDS unless the read or the window holds an ambiguity letter (then the flag words are needed)
+			const int lane = threadIdx.x & 63;
+			const int64_t lo = ((int64_t)a.gpos - a.qa - DMAX - 16) >> 4; // window start, in 16-base words (may be negative: padding)
+			bool amb = false;
+			if (a.s.ra)
+				for (int w = lane; w < (a.L + 31) / 32; w += 64)
+					amb = amb || a.s.ra[w] != 0;
+			const int n_db = (a.L + 2 * DMAX + 48 + 15) / 16 + 1;
+			if (a.s.dba) {
+				if (v.amb_blk) {
+					const int64_t b0 = (lo * 16) >> kBlkShift, b1 = (lo * 16 + n_db * 16) >> kBlkShift;
+					for (int64_t bb = (b0 < 0 ? 0 : b0) + lane; bb <= b1; bb += 64)
+						amb = amb || ((v.amb_blk[bb >> 5] >> (bb & 31)) & 1u);
+				} else {
+					amb = true;
+				}
+			}
+			if (__ballot(amb) == 0ull) {
+				const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw), *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
+				for (int w = lane; w < a.L / 16 + 2; w += 64)
+					lds.rd[w] = gr[w];
+				for (int w = lane; w <= n_db; w += 64)
+					lds.db[w] = gd[w];
+				staged = true;
+				awin = (int)((int64_t)a.gpos - lo * 16);
+			}
+			lds_sync();
+		}
+		const bool okl = greedy_big<-1, DMAX>(&lds, a.s, staged, a.qa - 1, a.S0 + a.sa - 1, awin - 1, a.qa, a.sa, l);
 		lds_sync();
-		const bool okr = okl && greedy_big<+1, DMAX>(&lds, a.s, a.qa, a.S0 + a.sa, a.L - a.qa, a.slen - a.sa, r);
+		const bool okr = okl && greedy_big<+1, DMAX>(&lds, a.s, staged, a.qa, a.S0 + a.sa, awin, a.L - a.qa, a.slen - a.sa, r);
 		lds_sync();
 		if ((threadIdx.x & 63) == 0) {
 			if (okl && okr) {
@@ -817,13 +925,16 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const unsigned long long want = long_reads ? hit_cap + ovf_cap : (1ull << 20);
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
-	PGX_TRY(gw.big_list2.ensure(big_cap));
-	PGX_TRY(gw.big_count.ensure(2));
+	PGX_TRY(gw.big_count.ensure(4));
 	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
 	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
 	PGX_TRY(gw.order.ensure((size_t)10240 * kBlkItems));
+	// (the list may have been grown by the caller after a step that overflowed it: the later tiers' lists and the parked
+	// sides of the second tier follow ITS size, not the first guess -- they are indexed by its entries)
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
-	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 2 * sizeof(uint32_t), stream));
+	PGX_TRY(gw.big_list2.ensure(cap));
+	PGX_TRY(gw.side_list.ensure(long_reads ? 1 : cap));
+	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 4 * sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
 	const int dbg = getenv("PGX_GAP_DBG") ? atoi(getenv("PGX_GAP_DBG")) : 0; // (measurement aid)
@@ -832,11 +943,11 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	do {                                                                                                                                 \
 		v.key = main_key;                                                                                                            \
 		const unsigned grid_wv = std::min<unsigned>(grid, 256u * 4u * WV * 2u); /* two full rounds of resident wavefronts */  \
-		hipLaunchKernelGGL((k_gapped_fast<false, ML, WV>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
+		hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
 				   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
 		v.key = ovf_key;                                                                                                             \
-		hipLaunchKernelGGL((k_gapped_fast<true, ML, WV>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,               \
+		hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,          \
 				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
 				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
 	} while (0)
@@ -849,10 +960,19 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	else
 		PGX_GAPPED_LAUNCH(512, 2);
 #undef PGX_GAPPED_LAUNCH
-	// the listed HSPs: first with rows for 62 differences a side, the rest (their own, shorter list) with rows for 1 000
-	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, gw.big_list.data(), gw.big_count.data(), cap,
-			   gw.big_list2.data(), gw.big_count.data() + 1);
-	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, gw.big_list2.data(), gw.big_count.data() + 1, cap,
+	// the listed HSPs, tier by tier, each passing on what it cannot hold: the lane-per-HSP kernel again with rows for 40
+	// differences a side and the X-drop history (reads of <= 512 bases without ambiguity letters: most of what reads of
+	// 300-500 bases list), then one wavefront per HSP with rows for 62 differences, then for the spec's 1 000
+	if (!long_reads)
+		hipLaunchKernelGGL((k_gapped_fast<2, 512, 2, kGFastD2>), dim3(256 * 6 * 2), dim3(64), 0, stream, v,
+				   reinterpret_cast<pgx_hit *>(gw.big_list.data()), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
+				   reinterpret_cast<const unsigned long long *>(gw.big_count.data()), gw.big_list2.data(), gw.big_count.data() + 1, cap,
+				   gw.side_list.data(), 0, gw.order.data());
+	const unsigned long long *l62 = long_reads ? gw.big_list.data() : gw.big_list2.data();
+	unsigned long long *l1000 = long_reads ? gw.big_list2.data() : gw.big_list.data();
+	const uint32_t *c62 = gw.big_count.data() + (long_reads ? 0 : 1);
+	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, l62, c62, cap, l1000, gw.big_count.data() + 2);
+	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)l1000, gw.big_count.data() + 2, cap,
 			   (unsigned long long *)nullptr, (uint32_t *)nullptr);
 	PGX_HIP(hipGetLastError());
 	return 0;

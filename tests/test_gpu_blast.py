@@ -628,3 +628,49 @@ def test_reads_with_long_unknown_runs_are_searched_in_pieces(pg, oracle_bin, tmp
     assert _blast_text(pg, db, rd, tmp_path, "pieces") == want.read_bytes()
     monkeypatch.setenv("PGX_NO_PIECES", "1")
     assert _blast_text(pg, db, rd, tmp_path, "whole") == want.read_bytes()
+
+
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_TIER2_SEEDS", "71,72").split(",")])
+def test_reads_of_350_to_500_bases_with_19_to_40_differences_a_side(pg, oracle_bin, tmp_path, seed):
+    """The second tier of the lane-per-HSP kernel (rows for 40 differences a side, the X-drop history from 19 on): reads of
+    350-500 bases, 6-10 % away from their sources, with indels: most sides need more than 18 differences."""
+    import random
+    from pangea_plus_amd import _capi
+    rng = random.Random(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    anc = "".join(rng.choice("ACGT") for _ in range(1600))
+    seqs = []
+    for i in range(40):
+        s = list(anc)
+        for p_ in rng.sample(range(len(s)), 20 + (i % 4) * 20):
+            s[p_] = rng.choice("ACGT")
+        seqs.append("".join(s))
+    db = tmp_path / "fam.fa"
+    db.write_text("".join(">gi|%d|x|s%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    reads = []
+    for i in range(300):
+        L = rng.choice([350, 450, 500, 512])
+        s = rng.choice(seqs)
+        o = rng.randrange(0, len(s) - L)
+        w = list(s[o:o + L])
+        for p_ in rng.sample(range(len(w)), int(len(w) * rng.choice([0.05, 0.07, 0.09]))):
+            w[p_] = rng.choice("ACGT")
+        for _ in range(rng.choice([0, 1, 2, 4])):
+            p_ = rng.randrange(40, len(w) - 40)
+            if rng.random() < 0.5:
+                del w[p_:p_ + rng.choice([1, 2, 3])]
+            else:
+                w[p_:p_] = [rng.choice("ACGT") for _ in range(rng.choice([1, 2, 3]))]
+        w = "".join(w)[:512]
+        if i % 2:
+            w = "".join(comp[c] for c in reversed(w))
+        reads.append(">t%d\n%s\n" % (i, w))
+    rd = tmp_path / "tier2_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "tier2_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want), "-num_threads", "8"],
+                   timeout=900)[0] == 0
+    rows = want.read_bytes().splitlines()
+    assert len(rows) > 5000 and max(int(r.split(b"\t")[4]) for r in rows) >= 38   # mismatches of a row: both sides deep
+    assert _blast_text(pg, db, rd, tmp_path, "tier2") == want.read_bytes()
+    assert _capi.stage_times().gapped_wide > 1000   # the first tier listed them
