@@ -9,13 +9,15 @@
 // (S2 = i + j - 6 d).  R(d, k) = furthest i on diagonal k = i - j with d differences; the rules the paper leaves open
 // are stated in DESIGN.md (spec v2) and restated by the checker in oracle/o_gapped.c.
 //
-// Two kernels, the same results:
-//   k_gapped_fast  one LANE per HSP side (reads of <= 512 bases, <= 18 differences per side): loops over the difference
-//                  count d and the diagonal k are shared by the 64 lanes, the row R(d, .) of a lane is 39 registers
-//                  updated in place; a cell carries its own statistics (mismatches, gap openings, open-gap kind), so
-//                  there is no traceback.  Sides that need more go on a list.
-//   k_gapped_big   one WAVEFRONT per listed HSP, one lane per diagonal (64 at a time, <= 1000 differences per side), rows
-//                  double-buffered in LDS, the X-drop history, ambiguity flags.
+// Two kernels in four tiers, the same results; each tier lists what it cannot hold for the next:
+//   k_gapped_fast<0|1, MAXL, WAVES, 18>  one LANE per HSP side (reads of <= 512 bases, <= 18 differences per side): loops over
+//                  the difference count d and the diagonal k are shared by the 64 lanes, the row R(d, .) of a lane is 39
+//                  registers updated in place; a cell carries its own statistics (mismatches, gap openings, open-gap
+//                  kind), so there is no traceback.  No X-drop test is due below 19 differences.
+//   k_gapped_fast<2, 512, 2, 40>  the same code over the LIST of those HSPs with rows for 40 differences and the X-drop history
+//   k_gapped_big<62>   one WAVEFRONT per listed HSP, one lane per diagonal (64 at a time), rows double-buffered in LDS, the
+//                  X-drop history, ambiguity flags; rows for 62 differences a side (32 wavefronts per CU)
+//   k_gapped_big<1000> the same with rows for the spec's 1 000 differences (5 wavefronts per CU)
 // Both cut a cell whose score could not pass the best one even if every remaining letter matched.  The cut cannot change
 // the result (a child's bound is below its parent's, so no surviving cell has a cut parent; a cut cell never holds the
 // best score), which is why the sequential kernel, the parallel one (bound taken one step late) and the checker (no
