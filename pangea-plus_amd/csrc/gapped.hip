@@ -473,9 +473,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
 	const unsigned long long n_flat_raw = FLAT ? (LIST ? (unsigned long long)*reinterpret_cast<const uint32_t *>(flat_count) : *flat_count) : 0ull;
 	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
-	// (the second tier's list has no order to exploit: 64 entries, one round a side, per block -- with 2 048 the few listed
-	// HSPs of a short-read batch all fell to one or two wavefronts)
-	constexpr unsigned long long kItems = LIST ? 64ull : (unsigned long long)kBlkItems;
+	// (with 2 048 entries per block the few listed HSPs of a short-read batch all fell to one or two wavefronts)
+	// (LIST: 64 entries, one round a side, per block while the list is short, so that its HSPs spread over the chip; 512 --
+	// eight rounds ordered by the level estimate -- once there are enough of them to fill it several times over)
+	const unsigned long long kItems = LIST ? (n_flat > 64ull * 4ull * gridDim.x ? 512ull : 64ull) : (unsigned long long)kBlkItems;
 	const unsigned long long n_blocks = FLAT ? (n_flat + kItems - 1) / kItems : ((unsigned long long)n_reads + 63ull) / 64ull;
 
 	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -505,8 +506,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 		// the bucket of an HSP's side: the seed stage's level estimate (first tier: the key byte of its slot; second tier:
 		// the record's own columns, whose estimates are not cut at 15, moved down so that 16 .. 31 spread over the buckets)
 		auto key_of = [&](const pgx_hit *p, int side) -> uint32_t {
-			if (LIST) // (the record's estimates are cut at 15, which is where this tier's sides begin: no order to be had)
-				return (uint32_t)(side ? p->gapopen : p->mismatch) & 15u;
+			if (LIST) {
+				// the record's own estimates are cut at 15, where this tier's sides begin: the levels again from the record's
+				// B0 and the side's letters, floor((2 M - B0) / 5), 16 .. 31 spread over the buckets
+				const int anchor = p->qend, L = p->score, b0 = side ? (p->send >> 12) & 0x7FF : (p->send >> 1) & 0x7FF;
+				const int lv = (2 * (side ? L - anchor : anchor) - b0) / 5 - 16;
+				return (uint32_t)(b0 == 0 || lv > 15 ? 15 : (lv < 0 ? 0 : lv));
+			}
 			return (uint32_t)(v.key[p - table] >> (4 * side)) & 15u;
 		};
 		// item -> its record
