@@ -390,16 +390,18 @@ int reads_dust(pgx_reads *rd)
 	rd->has_dust = false;
 	if (n == 0)
 		return 0;
-	DevBuf<uint64_t> d_mask;
+	DevBuf<uint64_t> &d_mask = rd->d_dust_mask;
 	DevBuf<uint8_t> &d_any = rd->d_dust_any;
-	PGX_TRY(d_mask.alloc((size_t)rd->n_words + 24, 0, 0, true));
-	PGX_TRY(d_any.alloc(n));
+	DevBuf<uint32_t> &d_list = rd->d_dust_list, &d_list2 = rd->d_dust_list2, &d_nlist = rd->d_dust_n;
+	DevBuf<uint2> &d_range = rd->d_dust_range;
+	const size_t n_mask = (size_t)rd->n_words + 24;
+	PGX_TRY(d_mask.ensure(n_mask));
+	PGX_HIP(hipMemsetAsync(d_mask.data(), 0, n_mask * sizeof(uint64_t), 0));
+	PGX_TRY(d_any.ensure(n));
 	PGX_HIP(hipMemsetAsync(d_any.data(), 0, n, 0));
-	DevBuf<uint32_t> d_list, d_list2, d_nlist;
-	DevBuf<uint2> d_range;
-	PGX_TRY(d_list.alloc(n));
-	PGX_TRY(d_range.alloc(n));
-	PGX_TRY(d_nlist.alloc(2));
+	PGX_TRY(d_list.ensure(n));
+	PGX_TRY(d_range.ensure(n));
+	PGX_TRY(d_nlist.ensure(2));
 	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, 2 * sizeof(uint32_t), 0));
 	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
 	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
@@ -409,7 +411,7 @@ int reads_dust(pgx_reads *rd)
 	uint32_t n_listed[2] = { 0, 0 };
 	PGX_TRY(d_nlist.download(n_listed, 1));
 	if (n_listed[0]) {
-		PGX_TRY(d_list2.alloc(n_listed[0]));
+		PGX_TRY(d_list2.ensure(n_listed[0]));
 		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((n_listed[0] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb,
 				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, d_list.data(), d_nlist.data(), d_list2.data(), d_range.data(),
 				   d_nlist.data() + 1);
@@ -431,8 +433,10 @@ int reads_dust(pgx_reads *rd)
 		h_any.clear();
 		return 0; // no read of the batch has a masked base: the seed stage runs as without DUST
 	}
-	PGX_TRY(rd->d_dustwin_f.alloc((size_t)rd->n_words + 24, 0, 0, true));
-	PGX_TRY(rd->d_dustwin_r.alloc((size_t)rd->n_words + 24, 0, 0, true));
+	PGX_TRY(rd->d_dustwin_f.ensure(n_mask));
+	PGX_TRY(rd->d_dustwin_r.ensure(n_mask));
+	PGX_HIP(hipMemsetAsync(rd->d_dustwin_f.data(), 0, n_mask * sizeof(uint64_t), 0));
+	PGX_HIP(hipMemsetAsync(rd->d_dustwin_r.data(), 0, n_mask * sizeof(uint64_t), 0));
 	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, d_mask.data(), d_any.data(), rd->d_len.data(),
 			   rd->d_woff.data(), (uint32_t)n, rd->d_dustwin_f.data(), rd->d_dustwin_r.data());
 	PGX_HIP(hipGetLastError());

@@ -99,6 +99,10 @@ struct pgx_reads {
 	bool has_dust = false;
 	pgx::DevBuf<uint64_t> d_dustwin_f, d_dustwin_r;
 	pgx::DevBuf<uint8_t> d_dust_any; // per read: it has a masked base (the others skip the window bits)
+	// scratch of the DUST pass, kept with the batch so that a repeated pass (pgx_reads_redo_dust) allocates nothing
+	pgx::DevBuf<uint64_t> d_dust_mask;
+	pgx::DevBuf<uint32_t> d_dust_list, d_dust_list2, d_dust_n;
+	pgx::DevBuf<uint2> d_dust_range;
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
 	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the
 	// stretches between such runs (seqdb.hip: reads_build_pieces): `pieces` is a batch of its own, pieces of a read
