@@ -342,6 +342,14 @@ int pgx_trim_file(const pgx_trim_opts *o, char **log_text, char **fasta_text, si
  * can be measured against instead of the streaming bandwidth */
 int pgx_probe_gather(uint64_t table_bytes, int stream, double *lines_per_s, double *ms);
 
+/* diagnostics (tools/probe_issue.py, bench.py's roofline.issue): what a SIMD issues for the gapped stage's instruction
+ * mix, one instruction kind at a time (kinds 0..7: see csrc/probe.hip), with
+ * `waves_per_simd` (1..8) resident wavefronts.  out[0] = vector wave-instructions per second per SIMD, out[1] = shader
+ * cycles per vector instruction of one wavefront, out[2] = kernel ms, out[3] = shader clock (Hz).  The roof the gapped half of `blastn` (reference
+ * README.md:96) is measured against: that stage is instruction-bound, not memory-bound */
+int pgx_probe_issue(int waves_per_simd, int kind, double *out);
+const char *pgx_probe_issue_name(int kind); /* NULL past the last kind */
+
 /* instrumentation for bench.py: HIP-event time (ms) of the kernels of the last pipeline call */
 typedef struct {
 	float seed_extend_ms, group_ms, sort_ms, consensus_ms, total_ms;

@@ -95,7 +95,7 @@ SYMBOLS = [
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
-    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather",
+    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
 ]
 
 
@@ -140,6 +140,7 @@ def _declare(L):
     sig("pgx_megaclustable", C.c_int, [C.c_int, V, V])
     sig("pgx_trim_file", C.c_int, [V, V, V, V, V])
     sig("pgx_probe_gather", C.c_int, [C.c_uint64, C.c_int, V, V])
+    sig("pgx_probe_issue", C.c_int, [C.c_int, C.c_int, V])
     sig("pgx_blast_score_columns", C.c_int, [C.c_int32, I64, I64, I64, C.c_char_p, C.c_char_p])
     sig("pgx_free", None, [V])
     for name in ("pgx_db_close", "pgx_reads_close", "pgx_hits_close", "pgx_rdp_close", "pgx_tax_close"):

@@ -650,7 +650,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				// letter there -- so its ends bl, br ARE the best prefixes unless the drop-off of 10 stopped it early (then the
 				// bound is only lower, never wrong).  From it the number of LEVELS that stage will run on the side,
 				// floor((2 letters of the read on the side - B0) / 5): the work estimate its rounds are ordered by.
-				int b0l = 0, b0r = 0, kl = 15, kr = 15;
+				int b0l = 0, b0r = 0, kl = 14, kr = 14; // (estimates stop at 14: the key byte 0xFF marks a slot without a record)
 				if constexpr (Mask::kHasWindows) {
 					const int ml = M.count_range(bl, anchor), mr = M.count_range(anchor, br + 1);
 					b0l = ml <= 18 ? 2 * (anchor - bl) - 6 * ml : 0;
@@ -659,8 +659,8 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 					b0r = b0r > 0 && b0r < 2047 ? b0r : 0;
 					kl = (2 * anchor - b0l) / 5;
 					kr = (2 * (L - anchor) - b0r) / 5;
-					kl = kl < 15 ? kl : 15;
-					kr = kr < 15 ? kr : 15;
+					kl = kl < 14 ? kl : 14;
+					kr = kr < 14 ? kr : 14;
 				}
 				h.qstart = (int32_t)woff;
 				h.qend = anchor;
@@ -1966,8 +1966,11 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		cap = scratch.n;
 		ovf_cap = ovf.n;
 		if (dv.gapped) {
-			PGX_TRY(ws.scratch_key.ensure(cap));
+			// (16 bytes more: the binning kernels of the gapped stage read the keys as 16-byte words; 0xFF = no record in the slot --
+			// the tail of a wavefront's chunk of the table)
+			PGX_TRY(ws.scratch_key.ensure(cap + 16));
 			PGX_TRY(ws.ovf_key.ensure(ovf_cap));
+			PGX_HIP(hipMemsetAsync(ws.scratch_key.data(), 0xFF, cap + 16, st));
 		}
 		table_cap = out->d_hits.n;
 		PGX_HIP(hipMemsetAsync(ws.counters.data(), 0, kNCounters * sizeof(unsigned long long), st));
@@ -2033,7 +2036,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			ReadsView all = rv;
 			all.n = (uint32_t)ns;
 			PGX_TRY(gapped_stage(dv, all, scratch.data(), ws.scratch_key.data(), rs_ptr, rc_ptr, ovf.data(), ws.ovf_key.data(),
-					     ws.counters.data() + 4, ovf_cap, long_reads, cap, (int)sr->max_len, ws.gapped, st));
+					     ws.counters.data() + 4, ovf_cap, long_reads, cap, (int)sr->max_len, ws.gapped, st, ws.counters.data()));
 			trace_point("gapped_stage");
 		}
 		ws.ev.mark(2, st);

@@ -295,10 +295,11 @@ struct GappedWork {
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats), [1] of the second list
 	DevBuf<uint2> side_main, side_ovf, side_list; // per table slot (per list entry, second tier): the left side's extension, parked until the right side is done
 	DevBuf<uint32_t> order;            // per block of k_gapped_fast: the pool's HSPs in cost order
+	DevBuf<uint32_t> items, bins;      // binned form: the main table's slots in bin order; histogram, bin cursors, total
 };
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream);
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used);
 
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
 __host__ __device__ inline int pident_hundredths(int matches, int length)

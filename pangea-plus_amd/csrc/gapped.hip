@@ -430,15 +430,304 @@ __device__ __forceinline__ bool greedy_rows(const uint32_t *rdw, const uint32_t 
 	return !over;
 }
 
+// ------------------------------------------------------------------------------------------ the lean rows (first tier)
+// Round 3.  tools/probe_issue.py measured what a SIMD of this chip issues per instruction KIND (profiles/r03_issue_table.txt):
+// v_add / v_sub / v_and / v_or / v_xor / v_lshrrev / v_ashrrev / v_mov on registers and inline constants run at one
+// wavefront-instruction per ~2.2 cycles, EVERYTHING else (v_max3, v_min, v_cmp, v_cndmask, v_alignbit, v_ffbl, v_bfe,
+// v_lshlrev, any three-operand form, anything with a scalar-register or SDWA operand) at one per ~4.1.  The cell step above
+// is ~55 vector instructions, most of the second kind: ~200 SIMD cycles per cell step of the 281 measured, so the stage
+// IS vector-bound, and what helps is fewer and cheaper instructions per cell.  This form of the cell:
+//   * the cell word is  i << 17 | 0 << 16 | priority << 14 | G1  (G1 = gap columns in the subject row on the path).  The
+//     other statistics FOLLOW: on diagonal k the path holds G1 - k gap columns in the query row, a level is one difference,
+//     so mismatches = d - gap columns; gap OPENINGS are the gap columns while there is at most one of each kind (the
+//     greedy rule picks an insertion + deletion pair over two mismatches in 9 % of the bench's HSPs: the furthest row
+//     counts, not the score).  A side whose best cell holds two or more gap columns of ONE kind (1 %) is handed to the next tier, which carries the full statistics (the cells, their
+//     order and the best cell are the same with or without the statistics: nothing below the priority takes part in a
+//     comparison that can tie).  No traceback, no per-cell statistics update.
+//   * with bit 16 clear, (word + Q) >> 16 IS the bit offset of read letter i in the lane's staged letters, (word + Q) >> 13
+//     its byte offset in the TRANSPOSED letter rows (row r of lane l at r * 256 + l * 4: a lane always reads its own LDS
+//     bank, whatever the other lanes' rows are -- the per-lane rows of the first form conflicted 2.4 x per read);
+//     the database letter's offsets are the same word plus a per-diagonal constant.
+//   * a dead cell is i = -4 (not -32768): its candidates stay negative, and every address a dead or out-of-range cell forms
+//     stays inside the lane's rows (two spare rows in front), so no cell is branched around: the letters are fetched and
+//     compared for all 64 lanes and a select writes the dead ones -- straight code the compiler interleaves across cells,
+//     the LDS latency of one cell behind the arithmetic of the next.
+//   * the best cell is a running MAXIMUM of  score << 16 | (2047 - cell order) << 5 | G1  (first cell in (d, k) order among
+//     equal scores), one add and one max per cell; the bound is taken once per level from it (the cut never changes a
+//     result, see the header; the oracle has no cut at all).
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef __attribute__((address_space(3))) char lds_byte;
+// (the rows' base stays a link-time constant that folds into the instruction's offset field; `off` = row * 256 | lane * 4)
+__device__ __forceinline__ uint32_t lds_ld(const lds_word *seq0, uint32_t off) { return *(const lds_word *)((const lds_byte *)seq0 + off); }
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
+#ifndef PGX_LEAN_GROUP
+#define PGX_LEAN_GROUP 2
+#endif
+#ifndef PGX_LEAN_WAVES
+#define PGX_LEAN_WAVES 4
+#endif
+constexpr int kLeanGroup = PGX_LEAN_GROUP; // cells computed as one piece of straight code (their LDS reads in flight together)
+constexpr uint32_t kLeanDead = 0xFFF80000u; // i = -4
+constexpr uint32_t kLeanFromCur = 0x28000u;  // i + 1, priority 2 (a mismatch on this diagonal)
+constexpr uint32_t kLeanFromPrev = 0x24001u; // i + 1, priority 1, one more gap column in the subject row (from k - 1)
+constexpr int kLeanFrontRows = 2;            // spare rows in front of a lane's letters
+
+// matching letters from bit offsets qb / db of the lane's staged letters on, as BITS (2 per letter): min(32, cap2, 2 run)
+__device__ __forceinline__ uint32_t lean_lcp(const lds_word *seq0, uint32_t lane4, uint32_t qb, uint32_t db, uint32_t cap2)
+{
+	const uint32_t qa = ((qb << 3) & 0xFFFFFF00u) | lane4, da = ((db << 3) & 0xFFFFFF00u) | lane4;
+	const uint32_t x = __builtin_amdgcn_alignbit(lds_ld(seq0, qa + 256), lds_ld(seq0, qa), qb) ^ __builtin_amdgcn_alignbit(lds_ld(seq0, da + 256), lds_ld(seq0, da), db);
+	const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+	return min3u(scan_low(y), 32u, cap2);
+}
+
+// status: 0 done, 1 cells alive after D differences (next tier), 2 the best cell holds two or more gap columns of a kind (next tier)
+// seq0 = the letter rows (row r of lane l at byte r * 256 + l * 4), lane4 = l * 4; QB / DB0 = bit offsets of the side's first read / database
+// letter there; M, N = letters of the read / of the subject on the side; b0 as for greedy_rows
+template <int D>
+__device__ __forceinline__ int greedy_rows_lean(const lds_word *seq0, uint32_t lane4, bool on, int QB, int DB0, int M, int N, int b0, Side &out)
+{
+	static_assert(D < kGLag && D < 32, "no X-drop history, 5-bit fields");
+	constexpr int kCells = 2 * D + 3, C = D + 1;
+	const int A2 = 2 * M + QB, B2 = 2 * N + QB; // ends of the two sequences as read bit offsets (B2 + 2 k on diagonal k)
+	// ---- the first run
+	int i2 = 0; // 2 i
+	if (on) {
+		for (;;) {
+			const int cap2 = min(2 * M, 2 * N) - i2;
+			if (cap2 <= 0)
+				break;
+			const uint32_t r2 = lean_lcp(seq0, lane4, (uint32_t)(QB + i2), (uint32_t)(DB0 + i2), (uint32_t)cap2);
+			i2 += (int)r2;
+			if (r2 < 32u)
+				break;
+		}
+	}
+	out.i = out.j = i2 >> 1;
+	out.s2 = i2;
+	out.mism = out.gopen = 0;
+	bool live = on && !(i2 == 2 * M || i2 == 2 * N);
+	uint32_t R[kCells];
+#pragma unroll
+	for (int c = 0; c < kCells; c++)
+		R[c] = kLeanDead;
+	R[C] = live ? (uint32_t)i2 << 16 : kLeanDead;
+	// order of a cell: d * 64 + k + 32 (the first run: 32); key = s2 << 16 | (2047 - order) << 5 | G1
+	int best_key = (i2 << 16) | ((2047 - 32) << 5);
+	const uint32_t Qc = (uint32_t)QB << 16;
+	const uint32_t D0 = (uint32_t)(DB0 - QB) << 16;
+	const uint32_t c17 = 0x20000u;
+	uint32_t prev = kLeanDead;
+	// per level, per lane: the diagonals k the bound lets live are lo1 .. lo1 + width (none: lo1 = 1 << 20)
+	int lo1 = 0;
+	uint32_t width = 0;
+	uint32_t alldead = 0xFFFFFFFFu; // AND of the level's new cells: negative while every one of them is dead
+	auto set_range = [&](int d) { // for level d, from the best score so far
+		const int best = max(best_key >> 16, b0 - 1);
+		const int lo = 6 * d - (2 * N - best) + 1, hi = (2 * M - best) - 6 * d - 1; // lo <= k <= hi
+		const bool some = lo <= hi;
+		lo1 = some ? lo : (1 << 20);
+		width = some ? (uint32_t)(hi - lo) : 0u;
+		return some && lo <= d && hi >= -d;
+	};
+	// running per-cell values of a level (k ascending): Dk = D0 - k << 17, Bk = B2 + 2 k, rk = k - lo1
+	uint32_t Dk = 0, rk = 0;
+	int Bk = 0;
+	auto level_start = [&](int d) {
+		Dk = D0 + ((uint32_t)d << 17);
+		Bk = B2 - 2 * d;
+		rk = (uint32_t)(-d - lo1);
+		prev = kLeanDead;
+		alldead = 0xFFFFFFFFu;
+	};
+	// one cell; c compile-time; ckd = -(k + 6 d) << 16 | (2047 - order) << 5, wave-uniform
+	auto cell = [&](auto cc, auto reach_c, int ckd, uint32_t &r2_out) {
+		constexpr int c = decltype(cc)::value;
+		constexpr int k = c - C;
+		constexpr int reach = decltype(reach_c)::value;
+		const uint32_t cur = R[c], nxt = R[c + 1];
+		int m3;
+		if constexpr (k < -reach)
+			m3 = (int)nxt; // the left edge of the level: only diagonal k + 1 can lead here
+		else if constexpr (k > reach)
+			m3 = (int)(prev + kLeanFromPrev); // the right edge: only diagonal k - 1
+		else if constexpr (k - 1 < -reach && k + 1 > reach)
+			m3 = (int)(cur + kLeanFromCur); // level 1, k = 0
+		else if constexpr (k - 1 < -reach)
+			m3 = max((int)(cur + kLeanFromCur), (int)nxt);
+		else if constexpr (k + 1 > reach)
+			m3 = max((int)(cur + kLeanFromCur), (int)(prev + kLeanFromPrev));
+		else
+			m3 = max((int)(cur + kLeanFromCur), max((int)(prev + kLeanFromPrev), (int)nxt));
+		const uint32_t t = (uint32_t)m3 + Qc, u = t + Dk;
+		const uint32_t qbit = (uint32_t)((int)t >> 16), dbit = (uint32_t)((int)u >> 16);
+		const uint32_t qa = ((t >> 13) & 0xFFFFFF00u) | lane4, da = ((u >> 13) & 0xFFFFFF00u) | lane4;
+		const int cap2 = min(A2, Bk) - (int)qbit;
+		const bool ok = ((m3 | cap2) >= 0) & (rk <= width);
+		const uint32_t x = __builtin_amdgcn_alignbit(lds_ld(seq0, qa + 256), lds_ld(seq0, qa), qbit) ^ __builtin_amdgcn_alignbit(lds_ld(seq0, da + 256), lds_ld(seq0, da), dbit);
+		const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+		const uint32_t r2 = min3u(scan_low(y), 32u, (uint32_t)cap2);
+		const uint32_t nc = ((uint32_t)m3 & 0xFFFF3FFFu) + (r2 << 16);
+		const uint32_t nv = ok ? nc : kLeanDead;
+		best_key = max(best_key, (int)(nv + (uint32_t)ckd));
+		alldead &= nv;
+		r2_out = r2;
+		prev = cur;
+		R[c] = nv;
+		Dk -= c17;
+		Bk += 2;
+		rk += 1u;
+	};
+	// a cell whose first 16 letters all matched and that has more to compare: slide on (rare off the alignment's own diagonal)
+	auto slide_on = [&](auto cc, int ckd, uint32_t r2) {
+		constexpr int c = decltype(cc)::value;
+		constexpr int k = c - C;
+		const uint32_t w = R[c];
+		bool more = (int)w >= 0 && r2 == 32u;
+		if (__ballot(more) == 0ull)
+			return;
+		int q2 = (int)w >> 16; // 2 i
+		while (more) {
+			const int cap2 = min(A2, B2 + 2 * k) - (QB + q2);
+			if (cap2 <= 0)
+				break;
+			const uint32_t rr = lean_lcp(seq0, lane4, (uint32_t)(QB + q2), (uint32_t)(DB0 + q2 - 2 * k), (uint32_t)cap2);
+			q2 += (int)rr;
+			more = rr == 32u;
+		}
+		const uint32_t nv = (int)w >= 0 ? ((uint32_t)q2 << 16) | (w & 0xFFFFu) : w;
+		R[c] = nv;
+		best_key = max(best_key, (int)(nv + (uint32_t)ckd));
+	};
+	// cells c0 .. c0 + n - 1 are dead for every lane: written so, the running values stepped past them
+	auto skip_group = [&](auto c0c, auto nc) {
+		constexpr int c0 = decltype(c0c)::value, n = decltype(nc)::value;
+		prev = R[c0 + n - 1];
+		static_for<0, n>([&](auto jc) { R[c0 + decltype(jc)::value] = kLeanDead; });
+		Dk -= c17 * (uint32_t)n;
+		Bk += 2 * n;
+		rk += (uint32_t)n;
+	};
+	auto ckd_of = [](int d, int k) { return (int)((uint32_t)(-(k + 6 * d)) << 16) | ((2047 - (d * 64 + k + 32)) << 5); };
+	bool done = false, over = false;
+	bool in_range = set_range(1);
+	live = live && in_range;
+	static_for<1, kGUnrollLevels + 1>([&](auto dc) {
+		constexpr int d = decltype(dc)::value;
+		if (!done) {
+			if (__ballot(live) == 0ull) {
+				done = true;
+			} else {
+				level_start(d);
+				// groups of cells: straight code, then the (rare) longer slides of the group; a group no lane's bound lets
+				// live (the dead half of a side's last levels) is written dead without looking
+				static_for<0, (2 * d + 1 + kLeanGroup - 1) / kLeanGroup>([&](auto gc) {
+					constexpr int c0 = C - d + kLeanGroup * decltype(gc)::value;
+					constexpr int n = (C + d + 1 - c0) < kLeanGroup ? (C + d + 1 - c0) : kLeanGroup;
+					if (__ballot(lo1 <= c0 + n - 1 - C && lo1 + (int)width >= c0 - C) == 0ull) {
+						skip_group(std::integral_constant<int, c0>{}, std::integral_constant<int, n>{});
+					} else {
+						uint32_t r2[kLeanGroup] = {};
+						uint32_t any32 = 0;
+						static_for<0, n>([&](auto jc) {
+							constexpr int c = c0 + decltype(jc)::value;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, d - 1>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							any32 |= r2[decltype(jc)::value];
+						});
+						if (__ballot((any32 & 32u) != 0u) != 0ull) {
+							static_for<0, n>([&](auto jc) {
+								constexpr int c = c0 + decltype(jc)::value;
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							});
+						}
+					}
+				});
+				const bool some = set_range(d + 1);
+				live = (int)alldead >= 0 && some;
+			}
+		}
+	});
+	for (int d = kGUnrollLevels + 1; !done && __ballot(live) != 0ull; d++) {
+		if (d > D) {
+			over = live;
+			break;
+		}
+		level_start(d);
+		// (the running values start at k = -d: cells left of it are skipped without a step)
+		static_for<0, (kCells - 2 + kLeanGroup - 1) / kLeanGroup>([&](auto gc) {
+			constexpr int c0 = 1 + decltype(gc)::value * kLeanGroup;
+			constexpr int n = (kCells - 1 - c0) < kLeanGroup ? (kCells - 1 - c0) : kLeanGroup;
+			if (!(c0 + n - 1 - C < -d || c0 - C > d)) {
+				if (c0 - C >= -d && c0 + n - 1 - C <= d) {
+					// the whole group lies inside the level: the same straight code as above
+					if (__ballot(lo1 <= c0 + n - 1 - C && lo1 + (int)width >= c0 - C) == 0ull) {
+						skip_group(std::integral_constant<int, c0>{}, std::integral_constant<int, n>{});
+					} else {
+						uint32_t r2[kLeanGroup] = {};
+						uint32_t any32 = 0;
+						static_for<0, n>([&](auto jc) {
+							constexpr int c = c0 + decltype(jc)::value;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, D>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							any32 |= r2[decltype(jc)::value];
+						});
+						if (__ballot((any32 & 32u) != 0u) != 0ull) {
+							static_for<0, n>([&](auto jc) {
+								constexpr int c = c0 + decltype(jc)::value;
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							});
+						}
+					}
+				} else {
+					// a group the level's ends cut through: cell by cell
+					static_for<0, n>([&](auto jc) {
+						constexpr int c = c0 + decltype(jc)::value;
+						constexpr int k = c - C;
+						if (!(k < -d || k > d)) {
+							uint32_t r2 = 0;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, D>{}, ckd_of(d, k), r2);
+							if (__ballot((r2 & 32u) != 0u) != 0ull)
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, k), r2);
+						}
+					});
+				}
+			}
+		});
+		const bool some = set_range(d + 1);
+		live = (int)alldead >= 0 && some;
+	}
+	// the best cell: score, where, its gap columns
+	const int s2 = best_key >> 16;
+	const int order = 2047 - ((best_key >> 5) & 2047);
+	const int bd = order >> 6, bk = (order & 63) - 32;
+	const int g1 = best_key & 31, g2 = g1 - bk;
+	out.i = (s2 + bk + 6 * bd) >> 1;
+	out.j = out.i - bk;
+	out.s2 = s2;
+	out.gopen = g1 + g2;
+	out.mism = bd - (g1 + g2);
+	if (over)
+		return 1;
+	// (a gap column in the subject row and one in the query row are two gaps; only two columns of one kind can be one gap or two)
+	return g1 >= 2 || g2 >= 2 ? 2 : 0;
+}
+
 constexpr int kBlkItems = 2048; // HSPs a wavefront orders at a time
 constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of the seed run, capped at 15
 
-template <int MAXL, int D> struct FastLds {
+template <int MAXL, int D, bool LEAN> struct FastLds {
 	static constexpr int kRd = MAXL / 16 + 2;                    // read strand, 16 bases per word
 	static constexpr int kDb = (MAXL + 2 * D + 48 + 15) / 16 + 1; // database window
 	static constexpr int kSeq = (kRd + kDb) | 1; // odd stride: lanes that use the same index hit different banks
 	static constexpr int kRing = D >= kGLag ? ((D - kGLag + 2) | 1) : 1; // the X-drop history of a lane (second tier)
-	uint32_t seq[64][kSeq];
+	static constexpr bool kLean = LEAN; // first tier: TRANSPOSED rows (row r of lane l at seq[r * 64 + l]), spare rows in front
+	static constexpr int kRows = kLeanFrontRows + kRd + kDb;
+	uint32_t seq[kLean ? kRows * 64 : 64 * kSeq];
 	int xring[D >= kGLag ? 64 : 0][kRing]; // (nothing in the first tier: 256 bytes more there cost a fifth wavefront its LDS)
 	uint32_t bucket[kKeyBuckets];
 	// (the pool's HSPs in cost order live in GLOBAL scratch, one array per block: with them here the kernel held 12.6 KB of
@@ -447,6 +736,38 @@ template <int MAXL, int D> struct FastLds {
 	// (no copy of the work keys: 2 KB more LDS costs a wavefront per SIMD, and the rows are bound by vector issue:
 	// 12.6 KB -> 14.7 KB per wavefront ran 24 -> 31 ms per 2 M reads; 1 024-HSP chunks fill the buckets too thinly: 31 ms)
 };
+
+// An HSP this tier cannot finish goes on the next tier's list.  Entries past the list's capacity are dropped -- the host
+// sees the count and repeats the step with a larger list -- but their records are still SEED records (word offsets and
+// work estimates where a hit has coordinates), which the stages behind must never read as hits: those are made harmless.
+__device__ __forceinline__ void neutral_hit(pgx_hit *hp)
+{
+	pgx_hit o = *hp;
+	o.qstart = o.qend = o.sstart = o.send = 1;
+	o.score = 0;
+	o.mismatch = o.gapopen = 0;
+	*hp = o;
+}
+
+// one atomic per call (a single address takes ~90 M atomics a second: one per listed HSP would cost more than the rows)
+__device__ __forceinline__ void list_append(bool fail, pgx_hit *hp, unsigned long long *__restrict__ list, uint32_t *__restrict__ count, uint32_t cap)
+{
+	const unsigned long long m = __ballot(fail);
+	if (m == 0ull)
+		return;
+	const int lane = threadIdx.x & 63, first = __ffsll((unsigned long long)m) - 1;
+	uint32_t base = 0;
+	if (lane == first)
+		base = atomicAdd(count, (uint32_t)__popcll(m));
+	base = __shfl(base, first);
+	if (fail) {
+		const uint32_t w = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		if (w < cap)
+			list[w] = (unsigned long long)(uintptr_t)hp;
+		else
+			neutral_hit(hp);
+	}
+}
 
 // FLAT: the table is a flat array of *count hits (overflow table); otherwise the hits of read r are the read_cnt[r] records
 // from read_start[r] of the seed stage's main table (kFragmented: they are in the overflow table).
@@ -466,11 +787,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 						     uint2 *__restrict__ side_res, int dbg, uint32_t *__restrict__ order_all)
 {
 	constexpr bool FLAT = MODE != 0, LIST = MODE == 2;
-	using Lds = FastLds<MAXL, D>;
+	constexpr bool LEAN = MODE != 2 && D < kGLag; // the first tier over the tables; over a list: the rows with the full statistics
+	using Lds = FastLds<MAXL, D, LEAN>;
 	__shared__ Lds lds;
 	uint32_t *order = order_all + (size_t)blockIdx.x * kBlkItems; // written and read by this wavefront only, through L2
 	const int lane = threadIdx.x & 63;
-	uint32_t *rdw = lds.seq[lane], *dbwin = rdw + Lds::kRd;
+	// word w of the lane's staged read letters / database window
+	uint32_t *rdw = LEAN ? &lds.seq[kLeanFrontRows * 64 + lane] : &lds.seq[lane * Lds::kSeq];
+	uint32_t *dbwin = LEAN ? rdw + Lds::kRd * 64 : rdw + Lds::kRd;
+	constexpr int WS = LEAN ? 64 : 1; // stride of a lane's words
 	const unsigned long long n_flat_raw = FLAT ? (LIST ? (unsigned long long)*reinterpret_cast<const uint32_t *>(flat_count) : *flat_count) : 0ull;
 	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
 	// (with 2 048 entries per block the few listed HSPs of a short-read batch all fell to one or two wavefronts)
@@ -479,6 +804,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 	const unsigned long long kItems = LIST ? (n_flat > 64ull * 4ull * gridDim.x ? 512ull : 64ull) : (unsigned long long)kBlkItems;
 	const unsigned long long n_blocks = FLAT ? (n_flat + kItems - 1) / kItems : ((unsigned long long)n_reads + 63ull) / 64ull;
 
+	// LEAN: the HSPs to hand on wait in the two spare rows in front of the letters (128 table slots; what a dead cell reads
+	// there is never used) and go to the list 64-128 at a time
+	uint32_t n_pend = 0;
+	auto flush_pend = [&]() {
+		if constexpr (LEAN) {
+			for (uint32_t e0 = 0; e0 < n_pend; e0 += 64) {
+				const bool mine = e0 + lane < n_pend;
+				pgx_hit *hp = table + (mine ? lds.seq[e0 + lane] : 0u);
+				list_append(mine, hp, big_list, big_count, big_cap);
+			}
+			n_pend = 0;
+			lds_sync();
+		}
+	};
 	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
 		uint32_t excl = 0, st = 0, T;
 		if (FLAT) {
@@ -506,6 +845,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 		// the bucket of an HSP's side: the seed stage's level estimate (first tier: the key byte of its slot; second tier:
 		// the record's own columns, whose estimates are not cut at 15, moved down so that 16 .. 31 spread over the buckets)
 		auto key_of = [&](const pgx_hit *p, int side) -> uint32_t {
+			if (LIST && D < kGLag)
+				return (uint32_t)(side ? p->gapopen : p->mismatch) & 15u; // (the HSPs the lean tier listed: its own estimates)
 			if (LIST) {
 				// the record's own estimates are cut at 15, where this tier's sides begin: the levels again from the record's
 				// B0 and the side's letters, floor((2 M - B0) / 5), 16 .. 31 spread over the buckets
@@ -623,9 +964,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 							if (side) {
 								// right of the anchor: the read from the anchor's word on, the window likewise
 								for (int w = a.qa >> 4; w < Lds::kRd; w++)
-									rdw[w] = gr[w];
+									rdw[w * WS] = gr[w];
 								for (int w = awin >> 4; w < Lds::kDb; w++)
-									dbwin[w] = gd[w];
+									dbwin[w * WS] = gd[w];
 								sq0 = a.qa;
 								sd0 = awin;
 							} else {
@@ -634,11 +975,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 								// words lands at 16 W - 1 - y, so the side starts at 16 W - (anchor position)
 								const int wr = (a.qa + 15) >> 4, wd = (awin + 15) >> 4;
 								for (int w = 0; w < wr; w++)
-									rdw[w] = __builtin_bitreverse32(gr[wr - 1 - w]);
-								rdw[wr] = 0u; // (the window of the last letters reads one word further)
+									rdw[w * WS] = __builtin_bitreverse32(gr[wr - 1 - w]);
+								rdw[wr * WS] = 0u; // (the window of the last letters reads one word further)
 								for (int w = 0; w < wd; w++)
-									dbwin[w] = __builtin_bitreverse32(gd[wd - 1 - w]);
-								dbwin[wd] = 0u;
+									dbwin[w * WS] = __builtin_bitreverse32(gd[wd - 1 - w]);
+								dbwin[wd * WS] = 0u;
 								sq0 = 16 * wr - a.qa;
 								sd0 = 16 * wd - awin;
 							}
@@ -648,13 +989,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 					lds_sync();
 					Side sd;
 					bool ok;
-					if (dbg == 2)
-						on = false; // (probe: everything but the rows)
-					if (dbg == 1) {
-						lds_sync();
-						continue; // (probe: ordering + staging only)
+					if constexpr (LEAN) {
+						// (a side whose best cell holds two or more gap columns goes on: the next tier carries the statistics)
+						ok = greedy_rows_lean<D>((const lds_word *)&lds.seq[0], (uint32_t)lane * 4u, on, 32 * kLeanFrontRows + 2 * sq0, 32 * (kLeanFrontRows + Lds::kRd) + 2 * sd0,
+									  side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd) == 0;
+					} else {
+						ok = greedy_rows<D>(rdw, dbwin, D >= kGLag ? &lds.xring[D >= kGLag ? lane : 0][0] : nullptr, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd);
 					}
-					ok = greedy_rows<D>(rdw, dbwin, D >= kGLag ? &lds.xring[D >= kGLag ? lane : 0][0] : nullptr, on, sq0, sd0, side ? a.L - a.qa : a.qa, side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, sd);
 					if (mine) {
 						if (side == 0) {
 							// parked: i | j << 10 | mismatches << 20 | gap openings << 26 ; gap columns | wide << 31
@@ -669,16 +1010,407 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 							l.gopen = (int)(parked.x >> 26);
 							l.s2 = l.i + l.j - 6 * (l.mism + (int)parked.y);
 							write_gapped(hp, h, a, l, sd);
+						}
+					}
+					if (side == 1) {
+						const bool fail = mine && !(on && ok);
+						if constexpr (LEAN) {
+							const unsigned long long fm = __ballot(fail);
+							if (fm != 0ull) {
+								lds_sync(); // (the rows' last reads of the front rows are done)
+								if (fail)
+									lds.seq[n_pend + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)(hp - table);
+								n_pend += (uint32_t)__popcll(fm);
+								lds_sync();
+								if (n_pend > 64u)
+									flush_pend();
+							}
 						} else {
-							const uint32_t w = atomicAdd(big_count, 1u);
-							if (w < big_cap)
-								big_list[w] = (unsigned long long)(uintptr_t)hp;
+							list_append(fail, hp, big_list, big_count, big_cap);
 						}
 					}
 					lds_sync();
 				}
 			}
 		}
+		flush_pend();
+	}
+}
+
+// ------------------------------------------------------------------------------------------ the main table, binned
+// Round 3, second finding.  With the lean rows the stage did NOT get faster: PMC (profiles/r03_*) shows what holds it --
+// 209 L2 misses per read (7.4 per HSP) at 39 G misses a second, 0.78 of what the chip delivers for random 64-byte lines
+// (pgx_probe_gather: 50 G/s).  The pool-per-wavefront form above touches every record three times (ordering, left pass,
+// right pass), parks the left result, and fetches an HSP's letters twice.  This form touches them ONCE:
+//   1. k_gap_hist / k_gap_bins / k_gap_scatter: a counting sort of the main table's SLOT NUMBERS by the seed stage's key
+//      byte (levels left | levels right << 4; 0xFF = no record there), streaming over the 1-byte keys only: 256 bins, the
+//      costliest first.  Every HSP of a bin runs the same number of levels on BOTH sides.
+//   2. k_gapped_rows: a wavefront takes 64 consecutive entries of the binned list, fetches each record once, stages the
+//      letters of both sides once (right part forward, left part reversed, each lane's areas packed behind one another
+//      in its column of the transposed rows), runs the lean rows left then right -- the lanes of a round finish both
+//      sides together because the bin says so -- and writes the finished hit over the record.  No ordering pass per
+//      wavefront, no cost-order scratch, no parked sides.
+// The overflow table (a handful of reads per batch) and the lists keep the pool form.
+constexpr int kGapBins = 256;
+
+__global__ __launch_bounds__(256) void k_gap_hist(const uint8_t *__restrict__ key, const unsigned long long *__restrict__ used, unsigned long long cap,
+						  uint32_t *__restrict__ hist)
+{
+	__shared__ uint32_t h[kGapBins];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const unsigned long long n = *used < cap ? *used : cap;
+	for (unsigned long long base = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += (unsigned long long)gridDim.x * 256 * 16) {
+		const uint4 kk = *reinterpret_cast<const uint4 *>(key + base); // (the array is padded to whole 16-byte words)
+		const uint32_t w[4] = { kk.x, kk.y, kk.z, kk.w };
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+			if (b != 0xFFu && base + j < n)
+				atomicAdd(&h[b], 1u);
+		}
+	}
+	__syncthreads();
+	if (h[threadIdx.x])
+		atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// bins[0 .. 255] = histogram (in), bins[256 .. 511] = write cursor of each bin (out), bins[512] = entries in all
+__global__ __launch_bounds__(256) void k_gap_bins(uint32_t *__restrict__ bins)
+{
+	__shared__ uint32_t cnt[kGapBins], rank_of[kGapBins], at_rank[kGapBins];
+	const int b = threadIdx.x;
+	cnt[b] = bins[b];
+	__syncthreads();
+	// costliest first: by levels left + levels right, descending; equal sums by bin number
+	const int cost = (b & 15) + (b >> 4);
+	int r = 0;
+	for (int o = 0; o < kGapBins; o++) {
+		const int co = (o & 15) + (o >> 4);
+		r += (co > cost) || (co == cost && o < b);
+	}
+	rank_of[b] = (uint32_t)r;
+	at_rank[r] = (uint32_t)b;
+	__syncthreads();
+	if (b == 0) {
+		uint32_t run = 0;
+		for (int q = 0; q < kGapBins; q++) {
+			const uint32_t bb = at_rank[q];
+			bins[kGapBins + bb] = run;
+			run += cnt[bb];
+		}
+		bins[2 * kGapBins] = run;
+	}
+}
+
+constexpr int kBinTile = 256 * 64; // slots a block bins at a time
+
+__global__ __launch_bounds__(256) void k_gap_scatter(const uint8_t *__restrict__ key, const unsigned long long *__restrict__ used, unsigned long long cap,
+						     uint32_t *__restrict__ bins, uint32_t *__restrict__ items)
+{
+	__shared__ uint32_t h[kGapBins], at[kGapBins];
+	const unsigned long long n = *used < cap ? *used : cap;
+	for (unsigned long long t0 = (unsigned long long)blockIdx.x * kBinTile; t0 < n; t0 += (unsigned long long)gridDim.x * kBinTile) {
+		h[threadIdx.x] = 0;
+		__syncthreads();
+		uint4 kk[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
+			kk[q] = base < n ? *reinterpret_cast<const uint4 *>(key + base) : make_uint4(~0u, ~0u, ~0u, ~0u);
+			const uint32_t w[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w };
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+				if (b != 0xFFu && base + j < n)
+					atomicAdd(&h[b], 1u);
+			}
+		}
+		__syncthreads();
+		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kGapBins + threadIdx.x], h[threadIdx.x]) : 0u;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
+			const uint32_t w[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w };
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+				if (b != 0xFFu && base + j < n)
+					items[atomicAdd(&at[b], 1u)] = (uint32_t)(base + j);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+template <int MAXL> struct RowsLds {
+	static constexpr int D = kGFastD;
+	static constexpr int kQ = MAXL / 16 + 4;                     // rows of a lane's read letters: right part, then left part reversed
+	static constexpr int kD = (MAXL + 2 * D + 32 + 60) / 16 + 3; // rows of its database letters, likewise
+	static constexpr int kRows = kLeanFrontRows + kQ + kD + 1;   // (one spare row behind: the last word's neighbour)
+	uint32_t seq[kRows * 64];
+};
+
+// One round of 64 HSPs, one per lane, both sides: the record once, the letters once (right part forward, left part
+// reversed, packed behind one another in the lane's column of the transposed rows), the lean rows left then right, the
+// finished hit over the record.  HSPs this tier cannot finish wait in the two front rows (`n_pend` table slots).
+template <int MAXL>
+__device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, pgx_hit *__restrict__ table, pgx_hit *hp, bool mine, uint32_t &n_pend,
+					  unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap)
+{
+	using Lds = RowsLds<MAXL>;
+	constexpr int D = kGFastD;
+	const int lane = threadIdx.x & 63;
+	const lds_word *seq0 = (const lds_word *)&lds.seq[0];
+	uint32_t *col = &lds.seq[lane]; // row r of this lane: col[r * 64]
+	const pgx_hit h = *hp;
+	const Anchor a = anchor_of(v, h);
+	bool on = mine && a.L <= MAXL;
+	if (on && a.s.ra) {
+		uint64_t any = 0;
+		for (int w = 0; w < (a.L + 31) / 32; w++)
+			any |= a.s.ra[w];
+		on = any == 0;
+	}
+	// the database window: from D + 16 bases left of where the read's first base would lie, in whole 16-base words
+	const int64_t lo = ((int64_t)a.gpos - a.qa - D - 16) >> 4; // (may be negative: front padding)
+	const int awin = (int)((int64_t)a.gpos - lo * 16);        // the anchor's position in it
+	if (on && a.s.dba) {
+		const int64_t b0 = (lo * 16) >> kBlkShift, b1 = (lo * 16 + (a.L + 2 * D + 64)) >> kBlkShift;
+		if (v.amb_blk) {
+			for (int64_t bb = b0 < 0 ? 0 : b0; bb <= b1; bb++)
+				on = on && !((v.amb_blk[bb >> 5] >> (bb & 31)) & 1u);
+		} else {
+			on = false;
+		}
+	}
+	int QB[2] = { 0, 0 }, DB0[2] = { 0, 0 };
+	{
+		// Letters come in 16-byte loads, the same words for every lane (so they stay in registers), and go to rows that
+		// differ per lane: right of the anchor forward from the anchor's word, left of it REVERSED (words in reverse order,
+		// bits reversed: the two bits of a letter swap in both sequences alike).  Word by word, the loads of round 3's
+		// first form asked L2 for every line eight times over (20 requests per HSP, 13 of them hits).
+		constexpr int NQ = (MAXL / 16 + 2 + 3) / 4, ND = ((MAXL + 2 * D + 62) / 16 + 2 + 3) / 4;
+		const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw);
+		const uint32_t *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
+		uint4 q4[NQ], d4[ND];
+		if (on) {
+#pragma unroll
+			for (int t = 0; t < NQ; t++)
+				q4[t] = *reinterpret_cast<const uint4 *>(gr + 4 * t);
+#pragma unroll
+			for (int t = 0; t < ND; t++)
+				d4[t] = *reinterpret_cast<const uint4 *>(gd + 4 * t);
+			const int wq0 = a.qa >> 4, wq1 = (a.L + 15) >> 4, wr = (a.qa + 15) >> 4;
+			const int rowR = kLeanFrontRows, rowL = rowR + (wq1 - wq0 + 1);
+			QB[1] = 32 * rowR + 2 * (a.qa & 15);
+			QB[0] = 32 * rowL + 2 * (16 * wr - a.qa);
+#pragma unroll
+			for (int w = 0; w < 4 * NQ; w++) {
+				const uint32_t val = w & 2 ? (w & 1 ? q4[w >> 2].w : q4[w >> 2].z) : (w & 1 ? q4[w >> 2].y : q4[w >> 2].x);
+				if (w >= wq0 && w <= wq1)
+					col[(rowR + w - wq0) * 64] = val;
+				if (w < wr)
+					col[(rowL + wr - 1 - w) * 64] = __builtin_bitreverse32(val);
+			}
+			col[(rowL + wr) * 64] = 0u; // (the window of the last letters reads one word further)
+			const int wd0 = awin >> 4, wd1 = ((awin + (a.L - a.qa) + D + 16) >> 4) + 1, wd = (awin + 15) >> 4;
+			const int rowDR = kLeanFrontRows + Lds::kQ, rowDL = rowDR + (wd1 - wd0 + 1);
+			DB0[1] = 32 * rowDR + 2 * (awin & 15);
+			DB0[0] = 32 * rowDL + 2 * (16 * wd - awin);
+#pragma unroll
+			for (int w = 0; w < 4 * ND; w++) {
+				const uint32_t val = w & 2 ? (w & 1 ? d4[w >> 2].w : d4[w >> 2].z) : (w & 1 ? d4[w >> 2].y : d4[w >> 2].x);
+				if (w >= wd0 && w <= wd1)
+					col[(rowDR + w - wd0) * 64] = val;
+				if (w < wd)
+					col[(rowDL + wd - 1 - w) * 64] = __builtin_bitreverse32(val);
+			}
+			col[(rowDL + wd) * 64] = 0u;
+		}
+	}
+	lds_sync();
+	Side sd[2];
+	bool ok = true;
+#pragma unroll 1
+	for (int side = 0; side < 2; side++) {
+		Side r;
+		const int st = greedy_rows_lean<D>(seq0, (uint32_t)lane * 4u, on, side ? QB[1] : QB[0], side ? DB0[1] : DB0[0], side ? a.L - a.qa : a.qa,
+						   side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, r);
+		ok = ok && st == 0;
+		if (side)
+			sd[1] = r;
+		else
+			sd[0] = r;
+	}
+	if (on && ok)
+		write_gapped(hp, h, a, sd[0], sd[1]);
+	const bool fail = mine && !(on && ok);
+	const unsigned long long fm = __ballot(fail);
+	lds_sync(); // (the rows' reads are done before the letters are replaced)
+	if (fm != 0ull) {
+		if (fail)
+			lds.seq[n_pend + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)(hp - table);
+		n_pend += (uint32_t)__popcll(fm);
+		lds_sync();
+		if (n_pend > 64u) {
+			for (uint32_t e0 = 0; e0 < n_pend; e0 += 64) {
+				const bool m2 = e0 + lane < n_pend;
+				list_append(m2, table + (m2 ? lds.seq[e0 + lane] : 0u), big_list, big_count, big_cap);
+			}
+			n_pend = 0;
+			lds_sync();
+		}
+	}
+}
+
+template <int MAXL>
+__device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restrict__ table, uint32_t &n_pend, unsigned long long *__restrict__ big_list,
+					  uint32_t *__restrict__ big_count, uint32_t big_cap)
+{
+	const int lane = threadIdx.x & 63;
+	for (uint32_t e0 = 0; e0 < n_pend; e0 += 64) {
+		const bool m2 = e0 + lane < n_pend;
+		list_append(m2, table + (m2 ? lds.seq[e0 + lane] : 0u), big_list, big_count, big_cap);
+	}
+	n_pend = 0;
+	lds_sync();
+}
+
+// the binned form (PGX_GAP_BINS=1): rounds of 64 consecutive entries of the binned slot list
+template <int MAXL, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_rows(GapView v, pgx_hit *__restrict__ table, const uint32_t *__restrict__ items,
+													  const uint32_t *__restrict__ bins, unsigned long long *__restrict__ big_list,
+													  uint32_t *__restrict__ big_count, uint32_t big_cap)
+{
+	__shared__ RowsLds<MAXL> lds;
+	const int lane = threadIdx.x & 63;
+	const uint32_t n_items = bins[2 * kGapBins];
+	const uint32_t n_rounds = (n_items + 63u) / 64u;
+	uint32_t n_pend = 0;
+	for (uint32_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+		const uint32_t idx = round * 64u + lane;
+		const bool mine = idx < n_items;
+		gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, n_pend, big_list, big_count, big_cap);
+	}
+	gap_flush<MAXL>(lds, table, n_pend, big_list, big_count, big_cap);
+}
+
+// The pool form, ONE pass (round 3): a wavefront takes the HSPs of 64 reads (FLAT: 2 048 entries of the overflow table),
+// orders them by the seed stage's two estimates -- levels left of the anchor, then levels right of it: a counting sort
+// over the 1-byte keys, 256 buckets that borrow the letter rows before the first round needs them -- and runs them 64 at
+// a time with gap_round.  What the binned form gave up is kept: the pool's records are neighbours (two to a line, the
+// second one an L2 hit) and its 64 reads' letters (5 KB) are fetched from memory once for their ~1 800 HSPs; what the
+// two-pass pools of round 2 paid is gone: the second fetch of every letter and record, the parked left sides.
+// 7.4 L2 misses per HSP there (and 7.2 binned: every record and read line a first touch) -> see profiles/r03_*.
+template <bool FLAT, int MAXL, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_pool(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
+													  const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
+													  uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
+													  unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count,
+													  uint32_t big_cap, uint32_t *__restrict__ order_all)
+{
+	__shared__ RowsLds<MAXL> lds;
+	static_assert(RowsLds<MAXL>::kRows * 64 >= 128 + kGapBins, "the buckets borrow the letter rows");
+	uint32_t *bucket = &lds.seq[128]; // (behind the two front rows, which hold the pending list)
+	uint32_t *order = order_all + (size_t)blockIdx.x * kBlkItems; // written and read by this wavefront only, through L2
+	const int lane = threadIdx.x & 63;
+	const unsigned long long n_flat_raw = FLAT ? *flat_count : 0ull;
+	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
+	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
+	uint32_t n_pend = 0;
+	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+		uint32_t excl = 0, st = 0, T;
+		if (FLAT) {
+			const unsigned long long left = n_flat - blk * kBlkItems;
+			T = (uint32_t)(left < (unsigned long long)kBlkItems ? left : (unsigned long long)kBlkItems);
+		} else {
+			const uint32_t r = (uint32_t)blk * 64u + lane;
+			uint32_t cnt = 0;
+			if (r < n_reads) {
+				st = read_start[r];
+				cnt = st == kFragmented ? 0u : read_cnt[r];
+				if ((unsigned long long)st + cnt > table_cap)
+					cnt = 0; // the table was too small for this read: the host repeats the step with a larger one
+			}
+			uint32_t incl = cnt;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint32_t t = __shfl_up(incl, dd);
+				if (lane >= dd)
+					incl += t;
+			}
+			excl = incl - cnt;
+			T = __shfl(incl, 63);
+		}
+		auto locate = [&](uint32_t item) -> pgx_hit * {
+			if (FLAT)
+				return table + blk * kBlkItems + item;
+			int o = 0;
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1) {
+				const int cand = o + step;
+				const uint32_t e = __shfl(excl, cand & 63);
+				if (cand < 64 && e <= item)
+					o = cand;
+			}
+			const uint32_t base = __shfl(st, o), ex = __shfl(excl, o);
+			return table + base + (item - ex);
+		};
+		// bucket of an HSP: levels left of the anchor first, then levels right of it (the key byte with its halves swapped)
+		auto bucket_of = [&](const pgx_hit *p) -> uint32_t {
+			const uint32_t k = v.key[p - table];
+			return ((k & 15u) << 4) | (k >> 4);
+		};
+		for (uint32_t chunk = 0; chunk < T; chunk += kBlkItems) {
+			const uint32_t n_it = T - chunk < (uint32_t)kBlkItems ? T - chunk : (uint32_t)kBlkItems;
+			for (int b = lane; b < kGapBins; b += 64)
+				bucket[b] = 0;
+			lds_sync();
+			for (uint32_t it = 0; it < n_it; it += 64) {
+				const uint32_t item = it + lane;
+				const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
+				if (item < n_it)
+					atomicAdd(&bucket[bucket_of(p)], 1u);
+			}
+			lds_sync();
+			{
+				// exclusive scan of the 256 counts: four consecutive buckets per lane
+				const uint32_t c0 = bucket[4 * lane], c1 = bucket[4 * lane + 1], c2 = bucket[4 * lane + 2], c3 = bucket[4 * lane + 3];
+				const uint32_t sum = c0 + c1 + c2 + c3;
+				uint32_t incl = sum;
+#pragma unroll
+				for (int dd = 1; dd < 64; dd <<= 1) {
+					const uint32_t t = __shfl_up(incl, dd);
+					if (lane >= dd)
+						incl += t;
+				}
+				const uint32_t e = incl - sum;
+				lds_sync();
+				bucket[4 * lane] = e;
+				bucket[4 * lane + 1] = e + c0;
+				bucket[4 * lane + 2] = e + c0 + c1;
+				bucket[4 * lane + 3] = e + c0 + c1 + c2;
+			}
+			lds_sync();
+			for (uint32_t it = 0; it < n_it; it += 64) {
+				const uint32_t item = it + lane;
+				const pgx_hit *p = locate(chunk + (item < n_it ? item : n_it - 1));
+				if (item < n_it) {
+					const uint32_t slot = atomicAdd(&bucket[bucket_of(p)], 1u);
+					__hip_atomic_store(&order[slot], item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			lds_sync();
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the order array is in L2 before any lane reads it back
+			for (uint32_t it = 0; it < n_it; it += 64) {
+				const bool mine = it + lane < n_it;
+				const uint32_t item = __hip_atomic_load(&order[mine ? it + lane : n_it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				gap_round<MAXL>(lds, v, table, locate(chunk + item), mine, n_pend, big_list, big_count, big_cap);
+			}
+		}
+		gap_flush<MAXL>(lds, table, n_pend, big_list, big_count, big_cap);
 	}
 }
 
@@ -916,7 +1648,7 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream)
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used)
 {
 	GapView v;
 	v.fwd = rv.fwd;
@@ -929,38 +1661,72 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	v.dba = dv.amb;
 	v.seq_off = dv.seq_off;
 	v.amb_blk = dv.amb ? dv.amb_blk : nullptr;
-	// HSPs the lane-per-HSP kernel passes on: a handful for sequencing reads, every one for long queries
-	const unsigned long long want = long_reads ? hit_cap + ovf_cap : (1ull << 20);
+	// HSPs the first tier passes on: those whose best cell holds two or more gap columns and those still alive at 18
+	// differences (about one in a hundred for substitution-only reads, more for reads with indels); every one for long queries
+	const unsigned long long want = long_reads ? hit_cap + ovf_cap : std::max<unsigned long long>(1ull << 20, (hit_cap + ovf_cap) / 16);
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
 	PGX_TRY(gw.big_count.ensure(4));
-	PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
-	PGX_TRY(gw.side_ovf.ensure(ovf_cap));
+	const bool binned = !long_reads && getenv("PGX_GAP_POOLS1") == nullptr; // (PGX_GAP_POOLS1=1: the one-pass pools, for comparison)
+	const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;                // (PGX_GAP_POOLS2=1: the two-pass pools, for comparison)
+	if (binned) {
+		PGX_TRY(gw.items.ensure(hit_cap)); // the main table's slots in bin order
+		PGX_TRY(gw.bins.ensure(2 * kGapBins + 4));
+	}
+	if (pools2) {
+		PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
+		PGX_TRY(gw.side_ovf.ensure(ovf_cap));
+	}
 	PGX_TRY(gw.order.ensure((size_t)10240 * kBlkItems));
 	// (the list may have been grown by the caller after a step that overflowed it: the later tiers' lists and the parked
-	// sides of the second tier follow ITS size, not the first guess -- they are indexed by its entries)
+	// sides of the list tiers follow ITS size, not the first guess -- they are indexed by its entries)
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list2.ensure(cap));
 	PGX_TRY(gw.side_list.ensure(long_reads ? 1 : cap));
 	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 4 * sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
-	const int dbg = getenv("PGX_GAP_DBG") ? atoi(getenv("PGX_GAP_DBG")) : 0; // (measurement aid)
-	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy)
+	const int dbg = 0; // (round 2's truncation probes are gone: a truncated stage leaves seed records where the stages behind expect hits)
+	if (binned) {
+		// the main table's slots by key byte, costliest bin first (three streaming passes over the 1-byte keys)
+		PGX_HIP(hipMemsetAsync(gw.bins.data(), 0, (2 * kGapBins + 4) * sizeof(uint32_t), stream));
+		hipLaunchKernelGGL(k_gap_hist, dim3(256 * 8), dim3(256), 0, stream, main_key, main_used, hit_cap, gw.bins.data());
+		hipLaunchKernelGGL(k_gap_bins, dim3(1), dim3(256), 0, stream, gw.bins.data());
+		hipLaunchKernelGGL(k_gap_scatter, dim3(256 * 8), dim3(256), 0, stream, main_key, main_used, hit_cap, gw.bins.data(), gw.items.data());
+	}
+	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
+	uint32_t *cnt = gw.big_count.data(); // [0] list A (checked by the caller), [1] B, [2] C (in A's buffer), [3] D (in B's)
+	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
+	// the two tables; then the rows with the full statistics over what they listed (list A), which lists for the wider tiers (B)
 #define PGX_GAPPED_LAUNCH(ML, WV)                                                                                                              \
 	do {                                                                                                                                 \
 		v.key = main_key;                                                                                                            \
 		const unsigned grid_wv = std::min<unsigned>(grid, 256u * 4u * WV * 2u); /* two full rounds of resident wavefronts */  \
-		hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
-				   read_start, read_cnt, n, (const unsigned long long *)nullptr, gw.big_list.data(), gw.big_count.data(), cap,  \
-				   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
+		if (binned)                                                                                                                  \
+			hipLaunchKernelGGL((k_gapped_rows<ML, (WV > 4 ? 4 : WV)>), dim3(256u * 4u * (WV > 4 ? 4 : WV) * 2u), dim3(64), 0, stream, v, main_table, \
+					   gw.items.data(), gw.bins.data(), listA, cnt, cap);                                                     \
+		else if (pools2)                                                                                                             \
+			hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
+					   read_start, read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap,  \
+					   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
+		else                                                                                                                         \
+			hipLaunchKernelGGL((k_gapped_pool<false, ML, (WV > 4 ? 4 : WV)>), dim3(std::max(1u, std::min<unsigned>(grid, 256u * 4u * (WV > 4 ? 4 : WV) * 2u))), dim3(64), 0, stream, \
+					   v, main_table, hit_cap, read_start, read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap, gw.order.data()); \
 		v.key = ovf_key;                                                                                                             \
-		hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,          \
-				   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, gw.big_list.data(),                    \
-				   gw.big_count.data(), cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
+		if (pools2)                                                                                                                  \
+			hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,          \
+					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, listA,                    \
+					   cnt, cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
+		else                                                                                                                         \
+			hipLaunchKernelGGL((k_gapped_pool<true, ML, (WV > 4 ? 4 : WV)>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,       \
+					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, listA, cnt, cap, gw.order.data()); \
+		if (!long_reads)                                                                                                             \
+			hipLaunchKernelGGL((k_gapped_fast<2, ML, WV, kGFastD>), dim3(256 * 4 * WV), dim3(64), 0, stream, v,                      \
+					   reinterpret_cast<pgx_hit *>(listA), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, \
+					   reinterpret_cast<const unsigned long long *>(cnt), listB, cnt + 1, cap, gw.side_list.data(), 0, gw.order.data()); \
 	} while (0)
 	if (max_len <= 160)
-		PGX_GAPPED_LAUNCH(160, 5);
+		PGX_GAPPED_LAUNCH(160, PGX_LEAN_WAVES);
 	else if (max_len <= 192)
 		PGX_GAPPED_LAUNCH(192, 4);
 	else if (max_len <= 320)
@@ -968,19 +1734,19 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	else
 		PGX_GAPPED_LAUNCH(512, 2);
 #undef PGX_GAPPED_LAUNCH
-	// the listed HSPs, tier by tier, each passing on what it cannot hold: the lane-per-HSP kernel again with rows for 40
-	// differences a side and the X-drop history (reads of <= 512 bases without ambiguity letters: most of what reads of
-	// 300-500 bases list), then one wavefront per HSP with rows for 62 differences, then for the spec's 1 000
+	// the wider tiers, each passing on what it cannot hold: the lane-per-HSP kernel with rows for 40 differences a side
+	// and the X-drop history (reads of <= 512 bases without ambiguity letters: most of what reads of 300-500 bases
+	// list), then one wavefront per HSP with rows for 62 differences, then for the spec's 1 000
 	if (!long_reads)
 		hipLaunchKernelGGL((k_gapped_fast<2, 512, 2, kGFastD2>), dim3(256 * 6 * 2), dim3(64), 0, stream, v,
-				   reinterpret_cast<pgx_hit *>(gw.big_list.data()), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
-				   reinterpret_cast<const unsigned long long *>(gw.big_count.data()), gw.big_list2.data(), gw.big_count.data() + 1, cap,
+				   reinterpret_cast<pgx_hit *>(listB), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
+				   reinterpret_cast<const unsigned long long *>(cnt + 1), listA, cnt + 2, cap,
 				   gw.side_list.data(), 0, gw.order.data());
-	const unsigned long long *l62 = long_reads ? gw.big_list.data() : gw.big_list2.data();
-	unsigned long long *l1000 = long_reads ? gw.big_list2.data() : gw.big_list.data();
-	const uint32_t *c62 = gw.big_count.data() + (long_reads ? 0 : 1);
-	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, l62, c62, cap, l1000, gw.big_count.data() + 2);
-	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)l1000, gw.big_count.data() + 2, cap,
+	const unsigned long long *l62 = listA;
+	unsigned long long *l1000 = listB;
+	const uint32_t *c62 = long_reads ? cnt : cnt + 2;
+	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, l62, c62, cap, l1000, cnt + 3);
+	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)l1000, cnt + 3, cap,
 			   (unsigned long long *)nullptr, (uint32_t *)nullptr);
 	PGX_HIP(hipGetLastError());
 	return 0;
