@@ -747,8 +747,19 @@ __global__ void k_revcomp(const uint64_t *__restrict__ fwd, const uint32_t *__re
 	}
 }
 
+// Where a read's packed words go.  A strand of up to 256 bases (8 words) never straddles a 64-byte line, longer ones start
+// on a line: the seed stage fetches both strands of every read and the gapped stage one strand per HSP, each as whole
+// lines -- 150-base reads (5 words) at a stride of 5 words straddled a line in three cases of five (1.6 lines per fetch;
+// MI355X delivers ~50 G random lines a second whatever their use).  Costs 3 words in 8 for 150-base reads (0.5 GB per 10 M).
+static inline uint64_t place_read_words(uint64_t cursor, uint64_t nw)
+{
+	if (nw > 8 || (cursor & 7) + nw > 8)
+		cursor = (cursor + 7) & ~7ull;
+	return cursor;
+}
+
 __global__ void k_synth_reads(uint64_t seed, uint64_t n_seq, uint32_t seq_len, uint64_t n_genus, uint64_t read_seed,
-			      uint32_t read_len, uint64_t first, uint64_t count, uint32_t words_per_read,
+			      uint32_t read_len, uint64_t first, uint64_t count, uint32_t words_per_read, uint32_t stride,
 			      uint64_t *__restrict__ fwd)
 {
 	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,7 +788,7 @@ __global__ void k_synth_reads(uint64_t seed, uint64_t n_seq, uint32_t seq_len, u
 			b = 3 - b;
 		out |= (uint64_t)b << (2 * k);
 	}
-	fwd[t] = out;
+	fwd[ri * stride + w] = out;
 }
 
 static int reads_build_classes(pgx_reads *rd)
@@ -1153,6 +1164,7 @@ static int reads_build_pieces(pgx_reads *rd, const unsigned char *d_letters, con
 	pc->h_woff.resize((size_t)np + 1);
 	uint64_t nw = 0;
 	for (uint32_t k = 0; k < np; k++) {
+		nw = place_read_words(nw, (pc->h_len[k] + 31) / 32);
 		pc->h_woff[k] = (uint32_t)nw;
 		nw += (pc->h_len[k] + 31) / 32;
 		pc->max_len = std::max<int32_t>(pc->max_len, (int32_t)pc->h_len[k]);
@@ -1263,6 +1275,7 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 	for (int64_t i = 0; i < count; i++) {
 		uint64_t L = rec_off[(size_t)(first + i) + 1] - rec_off[(size_t)(first + i)];
 		rd->h_len[(size_t)i] = (uint32_t)L;
+		nw = place_read_words(nw, (L + 31) / 32);
 		rd->h_woff[(size_t)i] = (uint32_t)nw;
 		nw += (L + 31) / 32;
 		if ((int32_t)L > rd->max_len)
@@ -1554,18 +1567,22 @@ int pgx_reads_from_synth(const pgx_synth_cfg *cfg, int64_t first, int64_t count,
 	rd->first = first;
 	rd->synthetic = true;
 	uint32_t wpr = ((uint32_t)cfg->read_len + 31) / 32;
-	rd->n_words = count * (int64_t)wpr;
+	// (equal reads: a fixed stride with the property of place_read_words)
+	const uint32_t stride = wpr <= 1 ? 1 : wpr <= 2 ? 2 : wpr <= 4 ? 4 : (wpr + 7u) & ~7u;
+	if ((uint64_t)count * stride >= 0xFFFFFFFFull)
+		return fail(PGX_E_LIMIT, "pgx_reads_from_synth: more than 2^32 words in one batch");
+	rd->n_words = count * (int64_t)stride;
 	rd->max_len = cfg->read_len;
 	rd->h_len.assign((size_t)count, (uint32_t)cfg->read_len);
 	rd->h_woff.resize((size_t)count + 1);
 	for (int64_t i = 0; i <= count; i++)
-		rd->h_woff[(size_t)i] = (uint32_t)(i * wpr);
+		rd->h_woff[(size_t)i] = (uint32_t)(i * stride);
 	int rc = rd->d_fwd.alloc((size_t)rd->n_words + 24, 0, 0, true);
 	if (rc == 0 && count > 0) {
 		uint64_t nt = (uint64_t)count * wpr;
 		hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, cfg->seed,
 				   (uint64_t)cfg->n_seq, (uint32_t)cfg->seq_len, (uint64_t)cfg->n_genus, cfg->read_seed,
-				   (uint32_t)cfg->read_len, (uint64_t)first, (uint64_t)count, wpr, rd->d_fwd.data());
+				   (uint32_t)cfg->read_len, (uint64_t)first, (uint64_t)count, wpr, stride, rd->d_fwd.data());
 		if (hipGetLastError() != hipSuccess)
 			rc = fail(PGX_E_NODEVICE, "k_synth_reads launch failed");
 	}
