@@ -100,6 +100,10 @@ int pgx_blastn_run(const pgx_blastn_opts *opts);
 /* the same switch for searches through a database handle (pgx_blast_search, pgx_classify_consensus): per handle */
 int pgx_db_set_ungapped(pgx_db *db, int ungapped);
 int pgx_db_set_dust(pgx_db *db, int dust); /* 1 (default): DUST-masked bases of the reads seed nothing; 0: `-dust no` */
+/* 1: every search through this handle computes the DUST window bits of its batch again, on the search's stream, as its
+ * first stage -- query masking as `blastn` runs it, inside the search (reference README.md:96); 0 (default): the bits made
+ * when the batch was imported are used (the same bits: they depend on the reads alone) */
+int pgx_db_set_dust_each_search(pgx_db *db, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Classify, SOAP verb  —  `soap -a reads -D ref.index -o out -p 8 -M 4` (README.md:134;
@@ -356,7 +360,8 @@ typedef struct {
 	int64_t probes, postings, candidates, hits;
 	int64_t survivors; /* postings that pass the duplicate filter and get a diagonal mask built */
 	float gapped_ms;     /* spec v2: the gapped stage between seed_extend and group */
-	int64_t gapped_wide; /* HSPs the one-wavefront-per-HSP kernel extended */
+	int64_t gapped_wide; /* HSPs the first tier of the gapped stage listed for the later ones */
+	float dust_ms;       /* S3d recomputed inside the search (pgx_db_set_dust_each_search), else 0; part of total_ms */
 } pgx_stage_times;
 int pgx_last_stage_times(pgx_stage_times *out);
 

@@ -55,7 +55,7 @@ class StageTimes(C.Structure):
     _fields_ = [("seed_extend_ms", C.c_float), ("group_ms", C.c_float), ("sort_ms", C.c_float),
                 ("consensus_ms", C.c_float), ("total_ms", C.c_float), ("probes", C.c_int64), ("postings", C.c_int64),
                 ("candidates", C.c_int64), ("hits", C.c_int64), ("survivors", C.c_int64), ("gapped_ms", C.c_float),
-                ("gapped_wide", C.c_int64)]
+                ("gapped_wide", C.c_int64), ("dust_ms", C.c_float)]
 
 
 class _DevArray(C.Structure):
@@ -87,7 +87,7 @@ VOTE_DTYPE = np.dtype([("depth", "<i4"), ("name", "<u4", (7,)), ("votes", "u1", 
 SYMBOLS = [
     "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_db_build", "pgx_db_open",
     "pgx_db_from_fasta", "pgx_db_close", "pgx_db_num_seqs", "pgx_db_num_bases", "pgx_db_seq_id",
-    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust",
+    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust", "pgx_db_set_dust_each_search",
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
@@ -115,6 +115,7 @@ def _declare(L):
     sig("pgx_db_seq_id", S, [V, I64])
     sig("pgx_db_subject_lineage", S, [V, I64])
     sig("pgx_db_set_ungapped", C.c_int, [V, C.c_int])
+    sig("pgx_db_set_dust_each_search", C.c_int, [V, C.c_int])
     sig("pgx_reads_count", I64, [V])
     sig("pgx_hits_count", I64, [V])
     sig("pgx_reads_from_synth", C.c_int, [V, I64, I64, V])
@@ -273,6 +274,10 @@ class Db(_Handle):
     def set_dust(self, flag=True):
         """`blastn -dust no` (flag False) for searches through this handle."""
         _check(lib().pgx_db_set_dust(self.ptr, 1 if flag else 0))
+
+    def set_dust_each_search(self, flag):
+        """S3d (query masking) recomputed inside every search through this handle, as BLAST runs it"""
+        _check(lib().pgx_db_set_dust_each_search(self.ptr, 1 if flag else 0))
 
     def bind_taxonomy(self, tax):
         _check(lib().pgx_db_bind_taxonomy(self.ptr, tax.ptr))

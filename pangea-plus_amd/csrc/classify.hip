@@ -360,6 +360,8 @@ struct WaveLds {
 struct OutView {
 	pgx_hit *main, *ovf;
 	uint8_t *main_key, *ovf_key; // gapped mode: per slot the work estimate of the gapped stage (mismatches left | right << 4)
+	uint8_t *main_reg;           // gapped mode: per slot of the main table the REGION of the database the anchor lies in (position >> reg_shift)
+	int reg_shift;
 	unsigned long long main_cap, ovf_cap;
 	// [0] main-table slots reserved (chunks), [1] probes, [2] postings, [3] seed runs, [4] overflow hits,
 	// [5] hits stored in the main table, [6] candidates that survive the duplicate filter
@@ -1089,8 +1091,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 											  : unpack_hit(st->chit[rs * SLOT_CAP + i], rs ? rB : rA))
 									     : st->hit[i];
 						dst[base + i] = hh;
-						if (db.gapped)
+						if (db.gapped) {
 							dkey[base + i] = seed_key(hh);
+							if (!fr)
+								ov.main_reg[base + i] = (uint8_t)((uint32_t)hh.sstart >> ov.reg_shift);
+						}
 					}
 				em += n;
 				if (!fr)
@@ -1785,7 +1790,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 
 // stage boundaries on the pipeline's stream; read only after the one synchronisation at the end of the step
 struct StageEvents {
-	static constexpr int kN = 6;
+	static constexpr int kN = 7;
 	hipEvent_t e[kN] = {};
 	bool ok = false;
 	int init()
@@ -1860,6 +1865,7 @@ struct Workspace {
 	unsigned long long *h_counters = nullptr; // pinned mirror of counters + the gapped stage's list count
 	DevBuf<pgx_hit> scratch, ovf;
 	DevBuf<uint8_t> scratch_key, ovf_key; // gapped mode: the gapped stage's work estimate per slot of the two tables
+	DevBuf<uint8_t> scratch_reg;          // gapped mode: database region of the anchor, per slot of the main table
 	DevBuf<uint32_t> partial, cursor, big_list, read_start, mid_list;
 	DevBuf<uint32_t> piece_cnt, piece_off, parent_start; // batches searched piece by piece
 	DevBuf<pgx_consensus_rec> recs;
@@ -1957,6 +1963,11 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	const ConsView cv = cons_view(db, rdp);
 	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
 	uint64_t H = 0, H_ovf = 0;
+	// S3d inside the search (pgx_db_set_dust_each_search): the window bits of the batch computed again, on this stream
+	ws.ev.mark(6, st);
+	const bool dust_now = db->dust && db->dust_each_search;
+	if (dust_now)
+		PGX_TRY(reads_dust_again(const_cast<pgx_reads *>(sr), st));
 	for (int attempt = 0;; attempt++) {
 		if (attempt > 8)
 			return fail(PGX_E_LIMIT, "hit tables did not settle after %d attempts", attempt);
@@ -1969,6 +1980,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			// (16 bytes more: the binning kernels of the gapped stage read the keys as 16-byte words; 0xFF = no record in the slot --
 			// the tail of a wavefront's chunk of the table)
 			PGX_TRY(ws.scratch_key.ensure(cap + 16));
+			PGX_TRY(ws.scratch_reg.ensure(cap + 16));
 			PGX_TRY(ws.ovf_key.ensure(ovf_cap));
 			PGX_HIP(hipMemsetAsync(ws.scratch_key.data(), 0xFF, cap + 16, st));
 		}
@@ -1979,6 +1991,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		ov.ovf = ovf.data();
 		ov.main_key = ws.scratch_key.data();
 		ov.ovf_key = ws.ovf_key.data();
+		ov.main_reg = ws.scratch_reg.data();
+		ov.reg_shift = gapped_region_shift(db->n_bases);
 		ov.main_cap = cap;
 		ov.ovf_cap = ovf_cap;
 		ov.counters = ws.counters.data();
@@ -2036,7 +2050,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			ReadsView all = rv;
 			all.n = (uint32_t)ns;
 			PGX_TRY(gapped_stage(dv, all, scratch.data(), ws.scratch_key.data(), rs_ptr, rc_ptr, ovf.data(), ws.ovf_key.data(),
-					     ws.counters.data() + 4, ovf_cap, long_reads, cap, (int)sr->max_len, ws.gapped, st, ws.counters.data()));
+					     ws.counters.data() + 4, ovf_cap, long_reads, cap, (int)sr->max_len, ws.gapped, st, ws.counters.data(), ws.scratch_reg.data()));
 			trace_point("gapped_stage");
 		}
 		ws.ev.mark(2, st);
@@ -2126,6 +2140,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	tm.group_ms = ws.ev.ms(2, 3);
 	tm.sort_ms = ws.ev.ms(3, 4);
 	tm.total_ms = ws.ev.ms(0, 4);
+	tm.dust_ms = dust_now ? ws.ev.ms(6, 0) : 0.0f;
+	tm.total_ms += tm.dust_ms;
 	// (PGX_HIT_LIMIT lowers the limit: tests use it to exercise the callers' batch halving)
 	const unsigned long long hit_limit = getenv("PGX_HIT_LIMIT") ? strtoull(getenv("PGX_HIT_LIMIT"), nullptr, 10) : (1ull << 32);
 	if (H >= hit_limit)
@@ -2232,6 +2248,14 @@ int pgx_classify_consensus_tri(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp,
 		fclose(f);
 	}
 	return pgx_classify_consensus(db, reads, rdp, hits_out, out, cap);
+}
+
+int pgx_db_set_dust_each_search(pgx_db *db, int on)
+{
+	if (!db)
+		return fail(PGX_E_ARG, "pgx_db_set_dust_each_search: null argument");
+	db->dust_each_search = on != 0;
+	return 0;
 }
 
 int pgx_db_set_ungapped(pgx_db *db, int ungapped)

@@ -442,6 +442,42 @@ int reads_dust(pgx_reads *rd)
 	PGX_HIP(hipGetLastError());
 	PGX_HIP(hipDeviceSynchronize());
 	rd->has_dust = true;
+	rd->dust_listed[0] = n_listed[0];
+	rd->dust_listed[1] = n_listed[1];
+	return 0;
+}
+
+// The same passes again on a resident batch, on `stream`, without a host wait: S3d as part of a search (BLAST masks its
+// queries inside every search; `pgx_db_set_dust_each_search`).  The masks depend on the reads alone, so the launch sizes the
+// first pass found (and the search classes made from its per-read flags) hold; the kernels take their counts on the device.
+int reads_dust_again(pgx_reads *rd, hipStream_t stream)
+{
+	const size_t n = (size_t)rd->n;
+	if (n == 0 || !rd->d_dust_mask.base)
+		return 0;
+	const size_t n_mask = (size_t)rd->n_words + 24;
+	PGX_HIP(hipMemsetAsync(rd->d_dust_mask.data(), 0, n_mask * sizeof(uint64_t), stream));
+	PGX_HIP(hipMemsetAsync(rd->d_dust_any.data(), 0, n, stream));
+	PGX_HIP(hipMemsetAsync(rd->d_dust_n.data(), 0, 2 * sizeof(uint32_t), stream));
+	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
+	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
+			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, rd->d_dust_list.data(),
+			   rd->d_dust_range.data(), rd->d_dust_n.data());
+	if (rd->dust_listed[0])
+		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((rd->dust_listed[0] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb,
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list.data(), rd->d_dust_n.data(), rd->d_dust_list2.data(),
+				   rd->d_dust_range.data(), rd->d_dust_n.data() + 1);
+	if (rd->dust_listed[1])
+		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((rd->dust_listed[1] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
+				   rd->d_woff.data(), rd->d_dust_list2.data(), rd->d_dust_range.data(), rd->d_dust_n.data() + 1, rd->d_dust_mask.data(),
+				   rd->d_dust_any.data());
+	if (rd->has_dust) {
+		PGX_HIP(hipMemsetAsync(rd->d_dustwin_f.data(), 0, n_mask * sizeof(uint64_t), stream));
+		PGX_HIP(hipMemsetAsync(rd->d_dustwin_r.data(), 0, n_mask * sizeof(uint64_t), stream));
+		hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, rd->d_dust_mask.data(), rd->d_dust_any.data(),
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dustwin_f.data(), rd->d_dustwin_r.data());
+	}
+	PGX_HIP(hipGetLastError());
 	return 0;
 }
 

@@ -36,6 +36,7 @@ struct pgx_db {
 	std::shared_ptr<void> work; // classify.hip: the handle's search workspace (stream, tables, counters), made on first use
 	std::mutex search_mu;       // searches through one handle are serialised; different handles share nothing
 	bool dust = true;      // pgx_db_set_dust: `-dust no` switches the low-complexity mask of the reads off
+	bool dust_each_search = false; // pgx_db_set_dust_each_search: S3d recomputed inside every search (as BLAST runs it), not only at import
 	bool ungapped = false; // pgx_db_set_ungapped: searches through this handle stop after the ungapped stage (spec v1)
 	pgx::DevBuf<uint32_t> d_bucket_off, d_postings;
 	// databases without ambiguity: 12-byte records {posting, database bases left of the 16-mer, bases right of it}, the
@@ -97,6 +98,7 @@ struct pgx_reads {
 	// spec v2 S3d (dust.hip): per strand one bit per read position: the 28 bases from there on touch no base that DUST
 	// masks; 64 positions per word at the read's word offset; absent when no read of the batch has a masked base
 	bool has_dust = false;
+	uint32_t dust_listed[2] = { 0, 0 }; // reads the first / second trigger pass listed when the batch was made
 	pgx::DevBuf<uint64_t> d_dustwin_f, d_dustwin_r;
 	pgx::DevBuf<uint8_t> d_dust_any; // per read: it has a masked base (the others skip the window bits)
 	// scratch of the DUST pass, kept with the batch so that a repeated pass (pgx_reads_redo_dust) allocates nothing
@@ -230,6 +232,7 @@ int choose_index_bits(int64_t n_postings);
 
 // dust.hip
 int reads_dust(pgx_reads *rd);
+int reads_dust_again(pgx_reads *rd, hipStream_t stream);
 
 // classify.hip
 struct SearchCounters {
@@ -295,11 +298,21 @@ struct GappedWork {
 	DevBuf<uint32_t> big_count; // [0] entries appended (may exceed the capacity: the caller grows and repeats), [1] of the second list
 	DevBuf<uint2> side_main, side_ovf, side_list; // per table slot (per list entry, second tier): the left side's extension, parked until the right side is done
 	DevBuf<uint32_t> order;            // per block of k_gapped_fast: the pool's HSPs in cost order
-	DevBuf<uint32_t> items, bins;      // binned form: the main table's slots in bin order; histogram, bin cursors, total
+	DevBuf<uint32_t> items, bins;      // binned form: the main table's slots in (region, bin) order; histograms, cursors, total
+	DevBuf<uint32_t> items1;           // ... in region order (first pass), with their key bytes
+	DevBuf<uint8_t> keys1;
 };
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used);
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used, const uint8_t *main_reg);
+// the main table's HSPs are handled region by region of the database (at most 240 regions: positions >> this)
+inline int gapped_region_shift(int64_t n_bases)
+{
+	int s = 0;
+	while (((n_bases + 1024) >> s) > 240)
+		s++;
+	return s;
+}
 
 // pident as printf("%.2f", 100.0*m/L) would print it, in hundredths (exact, ties via the double)
 __host__ __device__ inline int pident_hundredths(int matches, int length)

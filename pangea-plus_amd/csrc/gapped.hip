@@ -1050,96 +1050,180 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 //      in its column of the transposed rows), runs the lean rows left then right -- the lanes of a round finish both
 //      sides together because the bin says so -- and writes the finished hit over the record.  No ordering pass per
 //      wavefront, no cost-order scratch, no parked sides.
+//   3. (the step that paid most) the list is ordered by database REGION first (at most 240 regions of ~4 Mbases, a byte the
+//      seed stage writes beside the key), by key byte within a region: the wavefronts in flight work on one region at a
+//      time, ~1 MB of database words that stay in L2 -- every database line is fetched from memory once per step and
+//      XCD instead of once per HSP and side (2 of the 5.6 misses per HSP).
 // The overflow table (a handful of reads per batch) and the lists keep the pool form.
 constexpr int kGapBins = 256;
+// words of the sorting passes' table: [r] entries of region r, [kBaseAt + r] where they start, [kCurAt + r] scatter cursor,
+// [kTotalAt] entries in all, [kTileAt + r] tiles before region r (one more: all tiles), [kSegAt + r * 256 + b] entries
+// (then cursor) of key byte b within region r
+constexpr int kBaseAt = 256, kCurAt = 512, kTotalAt = 768, kTileAt = 1024, kSegAt = 2048, kBinsWords = kSegAt + 256 * kGapBins + 16;
+constexpr int kSegTile = 16384; // entries a block sorts at a time in the second pass
 
-__global__ __launch_bounds__(256) void k_gap_hist(const uint8_t *__restrict__ key, const unsigned long long *__restrict__ used, unsigned long long cap,
-						  uint32_t *__restrict__ hist)
+// valid slots per database region (key byte 0xFF: no record in the slot)
+__global__ __launch_bounds__(256) void k_reg_hist(const uint8_t *__restrict__ key, const uint8_t *__restrict__ reg, const unsigned long long *__restrict__ used,
+						  unsigned long long cap, uint32_t *__restrict__ bins)
 {
-	__shared__ uint32_t h[kGapBins];
+	__shared__ uint32_t h[256];
 	h[threadIdx.x] = 0;
 	__syncthreads();
 	const unsigned long long n = *used < cap ? *used : cap;
 	for (unsigned long long base = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += (unsigned long long)gridDim.x * 256 * 16) {
-		const uint4 kk = *reinterpret_cast<const uint4 *>(key + base); // (the array is padded to whole 16-byte words)
-		const uint32_t w[4] = { kk.x, kk.y, kk.z, kk.w };
+		const uint4 kk = *reinterpret_cast<const uint4 *>(key + base), rr = *reinterpret_cast<const uint4 *>(reg + base); // (padded to 16-byte words)
+		const uint32_t kw[4] = { kk.x, kk.y, kk.z, kk.w }, rw[4] = { rr.x, rr.y, rr.z, rr.w };
 #pragma unroll
 		for (int j = 0; j < 16; j++) {
-			const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+			const uint32_t b = (kw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
 			if (b != 0xFFu && base + j < n)
-				atomicAdd(&h[b], 1u);
+				atomicAdd(&h[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
 		}
 	}
 	__syncthreads();
 	if (h[threadIdx.x])
-		atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+		atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
 }
 
-// bins[0 .. 255] = histogram (in), bins[256 .. 511] = write cursor of each bin (out), bins[512] = entries in all
-__global__ __launch_bounds__(256) void k_gap_bins(uint32_t *__restrict__ bins)
+__global__ __launch_bounds__(256) void k_reg_bases(uint32_t *__restrict__ bins)
 {
-	__shared__ uint32_t cnt[kGapBins], rank_of[kGapBins], at_rank[kGapBins];
-	const int b = threadIdx.x;
-	cnt[b] = bins[b];
-	__syncthreads();
-	// costliest first: by levels left + levels right, descending; equal sums by bin number
-	const int cost = (b & 15) + (b >> 4);
-	int r = 0;
-	for (int o = 0; o < kGapBins; o++) {
-		const int co = (o & 15) + (o >> 4);
-		r += (co > cost) || (co == cost && o < b);
-	}
-	rank_of[b] = (uint32_t)r;
-	at_rank[r] = (uint32_t)b;
-	__syncthreads();
-	if (b == 0) {
-		uint32_t run = 0;
-		for (int q = 0; q < kGapBins; q++) {
-			const uint32_t bb = at_rank[q];
-			bins[kGapBins + bb] = run;
-			run += cnt[bb];
+	if (threadIdx.x == 0) {
+		uint32_t run = 0, tiles = 0;
+		for (int r = 0; r < 256; r++) {
+			bins[kBaseAt + r] = run;
+			bins[kCurAt + r] = run;
+			bins[kTileAt + r] = tiles;
+			run += bins[r];
+			tiles += (bins[r] + kSegTile - 1) / kSegTile;
 		}
-		bins[2 * kGapBins] = run;
+		bins[kTotalAt] = run;
+		bins[kTileAt + 256] = tiles;
 	}
 }
 
-constexpr int kBinTile = 256 * 64; // slots a block bins at a time
-
-__global__ __launch_bounds__(256) void k_gap_scatter(const uint8_t *__restrict__ key, const unsigned long long *__restrict__ used, unsigned long long cap,
-						     uint32_t *__restrict__ bins, uint32_t *__restrict__ items)
+// first pass: slot numbers (and their key bytes) by region
+__global__ __launch_bounds__(256) void k_reg_scatter(const uint8_t *__restrict__ key, const uint8_t *__restrict__ reg, const unsigned long long *__restrict__ used,
+						     unsigned long long cap, uint32_t *__restrict__ bins, uint32_t *__restrict__ items1, uint8_t *__restrict__ keys1)
 {
-	__shared__ uint32_t h[kGapBins], at[kGapBins];
+	__shared__ uint32_t h[256], at[256];
 	const unsigned long long n = *used < cap ? *used : cap;
-	for (unsigned long long t0 = (unsigned long long)blockIdx.x * kBinTile; t0 < n; t0 += (unsigned long long)gridDim.x * kBinTile) {
+	for (unsigned long long t0 = (unsigned long long)blockIdx.x * (256 * 64); t0 < n; t0 += (unsigned long long)gridDim.x * (256 * 64)) {
 		h[threadIdx.x] = 0;
 		__syncthreads();
-		uint4 kk[4];
+		uint4 kk[4], rr[4];
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
 			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
 			kk[q] = base < n ? *reinterpret_cast<const uint4 *>(key + base) : make_uint4(~0u, ~0u, ~0u, ~0u);
-			const uint32_t w[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w };
+			rr[q] = base < n ? *reinterpret_cast<const uint4 *>(reg + base) : make_uint4(0u, 0u, 0u, 0u);
+			const uint32_t kw[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w }, rw[4] = { rr[q].x, rr[q].y, rr[q].z, rr[q].w };
 #pragma unroll
 			for (int j = 0; j < 16; j++) {
-				const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+				const uint32_t b = (kw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
 				if (b != 0xFFu && base + j < n)
-					atomicAdd(&h[b], 1u);
+					atomicAdd(&h[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
 			}
 		}
 		__syncthreads();
-		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kGapBins + threadIdx.x], h[threadIdx.x]) : 0u;
+		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kCurAt + threadIdx.x], h[threadIdx.x]) : 0u;
 		__syncthreads();
 #pragma unroll
 		for (int q = 0; q < 4; q++) {
 			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
-			const uint32_t w[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w };
+			const uint32_t kw[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w }, rw[4] = { rr[q].x, rr[q].y, rr[q].z, rr[q].w };
 #pragma unroll
 			for (int j = 0; j < 16; j++) {
-				const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-				if (b != 0xFFu && base + j < n)
-					items[atomicAdd(&at[b], 1u)] = (uint32_t)(base + j);
+				const uint32_t b = (kw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+				if (b != 0xFFu && base + j < n) {
+					const uint32_t pos = atomicAdd(&at[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
+					items1[pos] = (uint32_t)(base + j);
+					keys1[pos] = (uint8_t)b;
+				}
 			}
 		}
+		__syncthreads();
+	}
+}
+
+// a tile of the second pass: up to kSegTile consecutive entries of ONE region
+__device__ __forceinline__ bool seg_tile(const uint32_t *__restrict__ bins, uint32_t tile, uint32_t &r, uint32_t &lo, uint32_t &hi)
+{
+	if (tile >= bins[kTileAt + 256])
+		return false;
+	uint32_t a = 0, b = 256; // the last region whose first tile is <= tile
+	while (b - a > 1) {
+		const uint32_t m = (a + b) / 2;
+		if (bins[kTileAt + m] <= tile)
+			a = m;
+		else
+			b = m;
+	}
+	r = a;
+	lo = bins[kBaseAt + r] + (tile - bins[kTileAt + r]) * (uint32_t)kSegTile;
+	const uint32_t end = bins[kBaseAt + r] + bins[r];
+	hi = lo + (uint32_t)kSegTile < end ? lo + (uint32_t)kSegTile : end;
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_seg_hist(const uint8_t *__restrict__ keys1, uint32_t *__restrict__ bins)
+{
+	__shared__ uint32_t h[256];
+	for (uint32_t tile = blockIdx.x;; tile += gridDim.x) {
+		uint32_t r, lo, hi;
+		if (!seg_tile(bins, tile, r, lo, hi))
+			break;
+		h[threadIdx.x] = 0;
+		__syncthreads();
+		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+			atomicAdd(&h[keys1[i]], 1u);
+		__syncthreads();
+		if (h[threadIdx.x])
+			atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], h[threadIdx.x]);
+		__syncthreads();
+	}
+}
+
+// one block per region: where each key byte's entries start, the costliest (levels left + levels right) first
+__global__ __launch_bounds__(256) void k_seg_bases(uint32_t *__restrict__ bins)
+{
+	__shared__ uint32_t cnt[kGapBins], at_rank[kGapBins];
+	const int b = threadIdx.x, r = blockIdx.x;
+	cnt[b] = bins[kSegAt + r * 256 + b];
+	const int cost = (b & 15) + (b >> 4);
+	int rank = 0;
+	for (int o = 0; o < kGapBins; o++) {
+		const int co = (o & 15) + (o >> 4);
+		rank += (co > cost) || (co == cost && o < b);
+	}
+	at_rank[rank] = (uint32_t)b;
+	__syncthreads();
+	if (b == 0) {
+		uint32_t run = bins[kBaseAt + r];
+		for (int q = 0; q < kGapBins; q++) {
+			const uint32_t bb = at_rank[q];
+			bins[kSegAt + r * 256 + bb] = run;
+			run += cnt[bb];
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__ keys1, const uint32_t *__restrict__ items1, uint32_t *__restrict__ bins,
+						     uint32_t *__restrict__ items2)
+{
+	__shared__ uint32_t h[256], at[256];
+	for (uint32_t tile = blockIdx.x;; tile += gridDim.x) {
+		uint32_t r, lo, hi;
+		if (!seg_tile(bins, tile, r, lo, hi))
+			break;
+		h[threadIdx.x] = 0;
+		__syncthreads();
+		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+			atomicAdd(&h[keys1[i]], 1u);
+		__syncthreads();
+		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], h[threadIdx.x]) : 0u;
+		__syncthreads();
+		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
+			items2[atomicAdd(&at[keys1[i]], 1u)] = items1[i];
 		__syncthreads();
 	}
 }
@@ -1281,18 +1365,32 @@ __device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restric
 // the binned form (PGX_GAP_BINS=1): rounds of 64 consecutive entries of the binned slot list
 template <int MAXL, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_rows(GapView v, pgx_hit *__restrict__ table, const uint32_t *__restrict__ items,
-													  const uint32_t *__restrict__ bins, unsigned long long *__restrict__ big_list,
+													  uint32_t *__restrict__ bins, unsigned long long *__restrict__ big_list,
 													  uint32_t *__restrict__ big_count, uint32_t big_cap)
 {
 	__shared__ RowsLds<MAXL> lds;
 	const int lane = threadIdx.x & 63;
-	const uint32_t n_items = bins[2 * kGapBins];
+	const uint32_t n_items = bins[kTotalAt];
+	uint32_t *next_round = bins + kTotalAt + 1; // (zero at launch)
 	const uint32_t n_rounds = (n_items + 63u) / 64u;
 	uint32_t n_pend = 0;
-	for (uint32_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
-		const uint32_t idx = round * 64u + lane;
-		const bool mine = idx < n_items;
-		gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, n_pend, big_list, big_count, big_cap);
+	// rounds are handed out in order, kRoundGrab at a time, from one counter: the wavefronts in flight then work on
+	// neighbouring rounds -- one or two database regions -- however unevenly they progress (with a fixed stride per
+	// wavefront they drifted tens of regions apart and the region order bought nothing)
+	constexpr uint32_t kRoundGrab = 8;
+	for (;;) {
+		uint32_t first = 0;
+		if (lane == 0)
+			first = atomicAdd(next_round, kRoundGrab);
+		first = __shfl(first, 0);
+		if (first >= n_rounds)
+			break;
+		const uint32_t last = first + kRoundGrab < n_rounds ? first + kRoundGrab : n_rounds;
+		for (uint32_t round = first; round < last; round++) {
+			const uint32_t idx = round * 64u + lane;
+			const bool mine = idx < n_items;
+			gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, n_pend, big_list, big_count, big_cap);
+		}
 	}
 	gap_flush<MAXL>(lds, table, n_pend, big_list, big_count, big_cap);
 }
@@ -1648,7 +1746,7 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
-		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used)
+		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used, const uint8_t *main_reg)
 {
 	GapView v;
 	v.fwd = rv.fwd;
@@ -1670,8 +1768,10 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const bool binned = !long_reads && getenv("PGX_GAP_POOLS1") == nullptr; // (PGX_GAP_POOLS1=1: the one-pass pools, for comparison)
 	const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;                // (PGX_GAP_POOLS2=1: the two-pass pools, for comparison)
 	if (binned) {
-		PGX_TRY(gw.items.ensure(hit_cap)); // the main table's slots in bin order
-		PGX_TRY(gw.bins.ensure(2 * kGapBins + 4));
+		PGX_TRY(gw.items.ensure(hit_cap)); // the main table's slots in (region, bin) order
+		PGX_TRY(gw.items1.ensure(hit_cap));
+		PGX_TRY(gw.keys1.ensure(hit_cap));
+		PGX_TRY(gw.bins.ensure(kBinsWords));
 	}
 	if (pools2) {
 		PGX_TRY(gw.side_main.ensure(hit_cap)); // the left side's result of every HSP, parked between the two passes
@@ -1688,11 +1788,16 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
 	const int dbg = 0; // (round 2's truncation probes are gone: a truncated stage leaves seed records where the stages behind expect hits)
 	if (binned) {
-		// the main table's slots by key byte, costliest bin first (three streaming passes over the 1-byte keys)
-		PGX_HIP(hipMemsetAsync(gw.bins.data(), 0, (2 * kGapBins + 4) * sizeof(uint32_t), stream));
-		hipLaunchKernelGGL(k_gap_hist, dim3(256 * 8), dim3(256), 0, stream, main_key, main_used, hit_cap, gw.bins.data());
-		hipLaunchKernelGGL(k_gap_bins, dim3(1), dim3(256), 0, stream, gw.bins.data());
-		hipLaunchKernelGGL(k_gap_scatter, dim3(256 * 8), dim3(256), 0, stream, main_key, main_used, hit_cap, gw.bins.data(), gw.items.data());
+		// the main table's slots by database region, within a region by key byte, costliest first: counting sorts that
+		// stream over one byte (then five) per slot
+		PGX_HIP(hipMemsetAsync(gw.bins.data(), 0, kBinsWords * sizeof(uint32_t), stream));
+		hipLaunchKernelGGL(k_reg_hist, dim3(256 * 8), dim3(256), 0, stream, main_key, main_reg, main_used, hit_cap, gw.bins.data());
+		hipLaunchKernelGGL(k_reg_bases, dim3(1), dim3(256), 0, stream, gw.bins.data());
+		hipLaunchKernelGGL(k_reg_scatter, dim3(256 * 8), dim3(256), 0, stream, main_key, main_reg, main_used, hit_cap, gw.bins.data(), gw.items1.data(),
+				   gw.keys1.data());
+		hipLaunchKernelGGL(k_seg_hist, dim3(256 * 8), dim3(256), 0, stream, gw.keys1.data(), gw.bins.data());
+		hipLaunchKernelGGL(k_seg_bases, dim3(256), dim3(256), 0, stream, gw.bins.data());
+		hipLaunchKernelGGL(k_seg_scatter, dim3(256 * 8), dim3(256), 0, stream, gw.keys1.data(), gw.items1.data(), gw.bins.data(), gw.items.data());
 	}
 	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
 	uint32_t *cnt = gw.big_count.data(); // [0] list A (checked by the caller), [1] B, [2] C (in A's buffer), [3] D (in B's)

@@ -14,6 +14,8 @@ pg.TaxDb.create(tmp)
 tax = pg.TaxDb.open(tmp)
 db = pg.Db.from_synth(cfg)
 db.bind_taxonomy(tax)
+if os.environ.get("QB_DUST", "1") != "0":
+    db.set_dust_each_search(True)
 reads = pg.Reads.from_synth(cfg, 0, n)
 rdp = pg.Rdp.from_synth(cfg, 0, n, db)
 rows = []
@@ -21,7 +23,7 @@ for i in range(steps + 2):
     _capi.classify_consensus(db, reads, rdp, want_records=False, want_hits=False)
     st = _capi.stage_times()
     if i >= 2:
-        rows.append((st.seed_extend_ms, st.gapped_ms, st.sort_ms, st.total_ms, st.hits, st.gapped_wide))
+        rows.append((st.seed_extend_ms, st.gapped_ms, st.sort_ms, st.total_ms, st.hits, st.gapped_wide, st.dust_ms))
 rows.sort(key=lambda r: r[3])
 m = rows[len(rows) // 2]
-print("reads=%d seed=%.2f gapped=%.2f sort=%.2f total=%.2f ms hits=%d wide=%d -> %.1f M reads/s" % (n, m[0], m[1], m[2], m[3], m[4], m[5], n / m[3] / 1e3), flush=True)
+print("reads=%d dust=%.2f seed=%.2f gapped=%.2f sort=%.2f total=%.2f ms hits=%d wide=%d -> %.1f M reads/s" % (n, m[6], m[0], m[1], m[2], m[3], m[4], m[5], n / m[3] / 1e3), flush=True)
