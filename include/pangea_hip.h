@@ -318,6 +318,8 @@ int pgx_megaclustable(int argc, const char *const *argv, char **log_text);
  * The reference's only record of its BLAST dependency's output, validation_dataset/Data-set_2_consensus.xlsx
  * (10 992 rows), is the known-answer set for it (tests/golden/blast_rows). */
 int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, char evalue[32], char bits[32]);
+/* the same with the statistics named: gapped != 0: spec S4 (the default search); 0: S4u, the columns of `blastn -ungapped` */
+int pgx_blast_score_columns_v(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, int gapped, char evalue[32], char bits[32]);
 
 /* --- the step before the path: Trim/trim2.4.pl == trim2.3.pl on FASTQ and QSEQ reads ---------
  * `perl trim2.3.pl -a reads_1 [-b reads_2] [-g GAP] [-t TRUNCATE]` (README.md:34; trim2.4.pl:46-167): the raw

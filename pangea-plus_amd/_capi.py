@@ -95,7 +95,7 @@ SYMBOLS = [
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
-    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
+    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_blast_score_columns_v", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
 ]
 
 
@@ -143,6 +143,7 @@ def _declare(L):
     sig("pgx_probe_gather", C.c_int, [C.c_uint64, C.c_int, V, V])
     sig("pgx_probe_issue", C.c_int, [C.c_int, C.c_int, V])
     sig("pgx_blast_score_columns", C.c_int, [C.c_int32, I64, I64, I64, C.c_char_p, C.c_char_p])
+    sig("pgx_blast_score_columns_v", C.c_int, [C.c_int32, I64, I64, I64, C.c_int, C.c_char_p, C.c_char_p])
     sig("pgx_free", None, [V])
     for name in ("pgx_db_close", "pgx_reads_close", "pgx_hits_close", "pgx_rdp_close", "pgx_tax_close"):
         sig(name, None, [V])
@@ -543,10 +544,11 @@ def megaclustable(argv):
     return text
 
 
-def blast_score_columns(score, qlen, db_len, db_nseq):
-    """(e-value text, bit-score text) of an -outfmt 6 row with raw score `score`, as the row formatter prints them."""
+def blast_score_columns(score, qlen, db_len, db_nseq, gapped=True):
+    """(e-value text, bit-score text) of an -outfmt 6 row with raw score `score`, as the row formatter prints them
+    (gapped=False: the statistics of `blastn -ungapped`, spec S4u)."""
     ev, bs = C.create_string_buffer(32), C.create_string_buffer(32)
-    _check(lib().pgx_blast_score_columns(int(score), int(qlen), int(db_len), int(db_nseq), ev, bs))
+    _check(lib().pgx_blast_score_columns_v(int(score), int(qlen), int(db_len), int(db_nseq), 1 if gapped else 0, ev, bs))
     return ev.value.decode(), bs.value.decode()
 
 

@@ -1220,7 +1220,7 @@ int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hit
 			// with the blank in front of a 3-digit bit score eaten by its split (taxcollector:77,148-153)
 			std::string line = reads->name_of(r) + "\t" + db->ids[(size_t)h.subject] + "\t";
 			cols.s.clear();
-			format_hit_columns(h, reads->h_len[(size_t)r], db->n_bases, db->n_seq, !db->ungapped, cols);
+			format_hit_columns(h, reads->h_len[(size_t)r], db->n_bases, db->n_seq, hits->gapped, cols);
 			line += cols.s;
 			emit_collected(line, db->lineage[(size_t)h.subject], out.s);
 		} else {

@@ -75,25 +75,52 @@ __global__ void k_big_keys(const pgx_hit *__restrict__ work, const uint32_t *__r
 	keys[g] = k;
 }
 
-// after pass 3 (subject asc, score desc inside a read): the head of a subject run carries the best score
+// after pass 3 (subject asc, score desc inside a read): the head of a subject run carries the best score.  The head of
+// every hit's run by a running maximum of "position if a run starts here" over the segment (a block scan per 256 hits with
+// a carry): linear in the segment however long a run is -- walking back to the head per hit was quadratic in the run
 __global__ __launch_bounds__(256) void k_big_best(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
 						   const uint32_t *__restrict__ seg_off, uint32_t n_big, uint32_t *__restrict__ best)
 {
+	__shared__ uint32_t s_head[256];
+	__shared__ uint32_t s_carry;
 	for (uint32_t k = blockIdx.x; k < n_big; k += gridDim.x) {
 		const uint32_t g0 = seg_off[k], g1 = seg_off[k + 1];
-		for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
-			const uint32_t v = vals[g];
-			const int subj = work[v].subject;
-			uint32_t h = g;
-			while (h > g0 && work[vals[h - 1]].subject == subj)
-				h--;
-			best[v] = (uint32_t)work[vals[h]].score;
+		if (threadIdx.x == 0)
+			s_carry = g0;
+		__syncthreads();
+		for (uint32_t c0 = g0; c0 < g1; c0 += 256) {
+			const uint32_t g = c0 + threadIdx.x;
+			uint32_t v = 0, head = 0;
+			if (g < g1) {
+				v = vals[g];
+				const bool starts = g == g0 || work[vals[g - 1]].subject != work[v].subject;
+				head = starts ? g + 1 : 0u; // (0: no run starts here)
+			}
+			s_head[threadIdx.x] = head;
+			__syncthreads();
+			for (int d = 1; d < 256; d <<= 1) {
+				const uint32_t o = (int)threadIdx.x >= d ? s_head[threadIdx.x - d] : 0u;
+				__syncthreads();
+				if (o > s_head[threadIdx.x])
+					s_head[threadIdx.x] = o;
+				__syncthreads();
+			}
+			const uint32_t carry = s_carry;
+			const uint32_t h = s_head[threadIdx.x] ? s_head[threadIdx.x] - 1 : carry;
+			if (g < g1)
+				best[v] = (uint32_t)work[vals[h]].score;
+			__syncthreads();
+			if (threadIdx.x == 255)
+				s_carry = h;
+			__syncthreads();
 		}
 	}
 }
 
 // Spec v2, S3c inside one subject run (hits in S5 order): a hit is dropped when an EARLIER hit of the run, on the same
 // strand, starts at the same point, ends at the same point, or holds it.  Dropped hits sort behind every kept one.
+// (The rule is pairwise by definition: the walk is over the earlier hits of the SAME (read, subject) run only and stops at
+// the first drop -- quadratic in the hits one read has on one subject, not in the read's hits.)
 __global__ __launch_bounds__(256) void k_big_dedup(const pgx_hit *__restrict__ work, const uint32_t *__restrict__ vals,
 						    const uint32_t *__restrict__ seg_off, uint32_t n_big, uint32_t *__restrict__ best,
 						    uint32_t *__restrict__ seg_drop)

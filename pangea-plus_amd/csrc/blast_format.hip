@@ -157,10 +157,16 @@ void format_score_columns(int score, int64_t qlen, int64_t db_len, int64_t db_ns
 // validation spreadsheet can be checked against the product itself (tests/test_gpu_blast_rows.py)
 extern "C" int pgx_blast_score_columns(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, char evalue[32], char bits[32])
 {
+	return pgx_blast_score_columns_v(score, qlen, db_len, db_nseq, 1, evalue, bits);
+}
+
+// the same with the statistics named: gapped != 0 = spec S4 (a table of a gapped search), 0 = S4u (`-ungapped`)
+extern "C" int pgx_blast_score_columns_v(int32_t score, int64_t qlen, int64_t db_len, int64_t db_nseq, int gapped, char evalue[32], char bits[32])
+{
 	if (!evalue || !bits || qlen <= 0 || db_len <= 0 || db_nseq <= 0)
 		return pgx::fail(PGX_E_ARG, "pgx_blast_score_columns: bad argument");
 	std::string e, b;
-	pgx::format_score_columns(score, qlen, db_len, db_nseq, true, e, b);
+	pgx::format_score_columns(score, qlen, db_len, db_nseq, gapped != 0, e, b);
 	snprintf(evalue, 32, "%s", e.c_str());
 	snprintf(bits, 32, "%s", b.c_str());
 	return 0;
@@ -186,7 +192,7 @@ static int format_hits_text_host(const pgx_hits *h, const pgx_db *db, const pgx_
 			out.s += '\t';
 			out.s += db->ids[(size_t)x.subject];
 			out.s += '\t';
-			format_hit_columns(x, qlen, db->n_bases, db->n_seq, !db->ungapped, out);
+			format_hit_columns(x, qlen, db->n_bases, db->n_seq, h->gapped, out);
 			out.s += '\n';
 		}
 	}
@@ -308,7 +314,7 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 	*p++ = '\n';
 }
 
-static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, std::vector<uint32_t> &len_slot,
+static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, bool gapped, std::vector<uint32_t> &len_slot,
 			      std::vector<uint32_t> &slot_base, std::vector<uint32_t> &score_off, std::string &score_blob);
 
 // renders the whole table; `sink` receives consecutive pieces of text
@@ -340,7 +346,7 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	// batch of long, all-different queries would need hundreds of millions of entries and is rendered by the host
 	std::vector<uint32_t> len_slot, slot_base, score_off;
 	std::string score_blob;
-	if (!build_score_table(db, reads, reads->n, false, len_slot, slot_base, score_off, score_blob)) {
+	if (!build_score_table(db, reads, reads->n, false, h->gapped, len_slot, slot_base, score_off, score_blob)) {
 		Text t;
 		PGX_TRY(format_hits_text_host(h, db, reads, t));
 		return sink(t.s.data(), t.s.size());
@@ -505,7 +511,7 @@ __global__ void k_fmt_consensus(ConsFmtView c, uint64_t r0, uint64_t r1, unsigne
 }
 
 // score-column table shared by the two renderers; false when it would be too large (see format_hits_stream)
-static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, std::vector<uint32_t> &len_slot,
+static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, bool gapped, std::vector<uint32_t> &len_slot,
 			      std::vector<uint32_t> &slot_base, std::vector<uint32_t> &score_off, std::string &score_blob)
 {
 	const uint32_t max_len = (uint32_t)reads->max_len;
@@ -527,7 +533,7 @@ static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t 
 		slot_base.push_back((uint32_t)score_off.size());
 		for (uint32_t sc = 0; sc <= L; sc++) {
 			score_off.push_back((uint32_t)score_blob.size());
-			format_score_columns((int)sc, L, db->n_bases, db->n_seq, !db->ungapped, ev, bs);
+			format_score_columns((int)sc, L, db->n_bases, db->n_seq, gapped, ev, bs);
 			score_blob += ev;
 			score_blob += '\t';
 			size_t b0 = 0;
@@ -547,7 +553,7 @@ bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx
 	*rc_out = 0;
 	std::vector<uint32_t> len_slot, slot_base, score_off;
 	std::string score_blob;
-	if (!build_score_table(db, reads, n, true, len_slot, slot_base, score_off, score_blob))
+	if (!build_score_table(db, reads, n, true, hits->gapped, len_slot, slot_base, score_off, score_blob))
 		return false;
 	auto run = [&]() -> int {
 		std::string lin_blob, name_blob;

@@ -1738,6 +1738,7 @@ static DbView db_view(const pgx_db *db)
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;
+	v.n_bases = db->n_bases;
 	v.bits = db->index_bits;
 	v.gapped = db->ungapped ? 0 : 1;
 	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0;
@@ -2129,6 +2130,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	ws.ovf_cap_hint = std::max<uint64_t>(ws.ovf_cap_hint, H_ovf + H_ovf / 16);
 	ws.table_hint = std::max<uint64_t>(ws.table_hint, H + H / 16);
 	out->n_hits = (int64_t)H;
+	out->gapped = dv.gapped != 0;
 	tm.hits = (int64_t)H;
 	tm.probes = (int64_t)h_cnt[1];
 	tm.postings = (int64_t)h_cnt[2];

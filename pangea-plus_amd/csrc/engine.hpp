@@ -119,6 +119,8 @@ struct pgx_reads {
 struct pgx_hits {
 	int64_t n_reads = 0;
 	int64_t n_hits = 0; // slots in d_hits (including hits dropped by the 500-subject limit)
+	bool gapped = true; // the search that made the table: spec v2 (gapped statistics, S4) or `-ungapped` (S4u) -- the formatter's
+			    // e-value / bit-score columns follow the TABLE, not the handle's switch at format time
 	pgx::DevBuf<pgx_hit> d_hits;     // grouped by read, spec order inside a read
 	pgx::DevBuf<uint32_t> d_read_off; // n_reads+1 slot offsets
 	pgx::DevBuf<uint32_t> d_read_cnt; // hits kept per read (<= slots of the read)
@@ -274,6 +276,7 @@ struct DbView {
 	const uint3 *post_ctx;
 	const uint32_t *amb_blk; // one bit per 512-base block with an ambiguity letter (null: the database has none)
 	uint32_t n_seq;
+	int64_t n_bases; // letters of all subjects (the packed words hold 768 zero letters in front and behind)
 	int bits;
 	int gapped;   // spec v2: the seed stage hands over initial HSPs (score field = offset of the seed run in the HSP) to gapped.hip
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work

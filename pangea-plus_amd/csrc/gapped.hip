@@ -154,6 +154,7 @@ struct GapView {
 	const uint32_t *len, *woff;
 	const uint64_t *dbw, *dba;
 	const uint32_t *seq_off;
+	int64_t db_bases;   // letters in the database (its packed words carry kDbPadBases zero letters in front and behind)
 	const uint8_t *key; // per slot of the table this launch works on: the seed stage's work estimate
 	const uint32_t *amb_blk; // one bit per 512-base block of the database that holds an ambiguity letter (or null)
 };
@@ -1174,8 +1175,14 @@ __global__ __launch_bounds__(256) void k_seg_hist(const uint8_t *__restrict__ ke
 			break;
 		h[threadIdx.x] = 0;
 		__syncthreads();
-		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-			atomicAdd(&h[keys1[i]], 1u);
+		// four entries per thread and step (a 4-byte word of keys; the list is padded to whole words)
+		for (uint32_t i0 = (lo & ~3u) + 4u * threadIdx.x; i0 < hi; i0 += 1024u) {
+			const uint32_t kw = *reinterpret_cast<const uint32_t *>(keys1 + i0);
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (i0 + j >= lo && i0 + j < hi)
+					atomicAdd(&h[(kw >> (8 * j)) & 0xFFu], 1u);
+		}
 		__syncthreads();
 		if (h[threadIdx.x])
 			atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], h[threadIdx.x]);
@@ -1217,13 +1224,32 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__
 			break;
 		h[threadIdx.x] = 0;
 		__syncthreads();
-		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-			atomicAdd(&h[keys1[i]], 1u);
+		constexpr int kSteps = kSegTile / 1024 + 1; // (a tile that starts inside a word reaches one step further)
+		uint32_t kw[kSteps];
+#pragma unroll
+		for (int q = 0; q < kSteps; q++) {
+			const uint32_t i0 = (lo & ~3u) + 4u * threadIdx.x + 1024u * q;
+			kw[q] = i0 < hi ? *reinterpret_cast<const uint32_t *>(keys1 + i0) : 0u;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (i0 + j >= lo && i0 + j < hi)
+					atomicAdd(&h[(kw[q] >> (8 * j)) & 0xFFu], 1u);
+		}
 		__syncthreads();
 		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], h[threadIdx.x]) : 0u;
 		__syncthreads();
-		for (uint32_t i = lo + threadIdx.x; i < hi; i += 256)
-			items2[atomicAdd(&at[keys1[i]], 1u)] = items1[i];
+#pragma unroll
+		for (int q = 0; q < kSteps; q++) {
+			const uint32_t i0 = (lo & ~3u) + 4u * threadIdx.x + 1024u * q;
+			if (i0 < hi) {
+				const uint4 it = *reinterpret_cast<const uint4 *>(items1 + i0);
+				const uint32_t iv[4] = { it.x, it.y, it.z, it.w };
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (i0 + j >= lo && i0 + j < hi)
+						items2[atomicAdd(&at[(kw[q] >> (8 * j)) & 0xFFu], 1u)] = iv[j];
+			}
+		}
 		__syncthreads();
 	}
 }
@@ -1532,6 +1558,7 @@ namespace pgx {
 // wavefronts per CU) for nearly every listed HSP, kGDmax = 1 000 (32 KB: 5 per CU) for the few sides that need more --
 // with the large rows only, reads of 300-500 bases, most of whose HSPs are listed, ran at 5 wavefronts per CU
 constexpr int kBigStageL = 2048; // reads up to this length have their letters staged in LDS by the small tier
+constexpr int kDbPadBases = 768; // zero letters in front of and behind the database's packed words (seqdb.hip: 24 words each)
 template <int DMAX> struct BigLds {
 	uint2 row[2][2 * DMAX + 3];
 	int ring[kGLag + 1]; // best score with at most d differences, for the last kGLag + 1 values of d
@@ -1717,7 +1744,11 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 					amb = true;
 				}
 			}
-			if (__ballot(amb) == 0ull) {
+			// (a long query that overhangs the first or the last subject by more than the padding: the window would begin
+			// before / end behind the packed words -- such an HSP reads its letters in memory, position by position, where
+			// the caps of the slides keep every access inside)
+			const bool inside = lo * 16 >= -(int64_t)kDbPadBases && (lo + n_db + 1) * 16 <= v.db_bases + kDbPadBases;
+			if (__ballot(amb) == 0ull && inside) {
 				const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw), *gd = reinterpret_cast<const uint32_t *>(a.s.dbw) + lo;
 				for (int w = lane; w < a.L / 16 + 2; w += 64)
 					lds.rd[w] = gr[w];
@@ -1758,6 +1789,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	v.dbw = dv.words;
 	v.dba = dv.amb;
 	v.seq_off = dv.seq_off;
+	v.db_bases = dv.n_bases;
 	v.amb_blk = dv.amb ? dv.amb_blk : nullptr;
 	// HSPs the first tier passes on: those whose best cell holds two or more gap columns and those still alive at 18
 	// differences (about one in a hundred for substitution-only reads, more for reads with indels); every one for long queries
@@ -1769,8 +1801,8 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;                // (PGX_GAP_POOLS2=1: the two-pass pools, for comparison)
 	if (binned) {
 		PGX_TRY(gw.items.ensure(hit_cap)); // the main table's slots in (region, bin) order
-		PGX_TRY(gw.items1.ensure(hit_cap));
-		PGX_TRY(gw.keys1.ensure(hit_cap));
+		PGX_TRY(gw.items1.ensure(hit_cap + 16)); // (read as 16-byte words / 4-byte words of keys)
+		PGX_TRY(gw.keys1.ensure(hit_cap + 16));
 		PGX_TRY(gw.bins.ensure(kBinsWords));
 	}
 	if (pools2) {

@@ -519,7 +519,7 @@ int pgx_megaclust_batch(const pgx_db *db, const pgx_reads *reads, const pgx_hits
 			seen[reads->h_len[(size_t)r]] = 1;
 		std::string evt, bst;
 		auto ok_score = [&](int score, uint32_t L) {
-			format_score_columns(score, L, db->n_bases, db->n_seq, !db->ungapped, evt, bst);
+			format_score_columns(score, L, db->n_bases, db->n_seq, hits->gapped, evt, bst);
 			return !(perl_num(evt) > p.ev) && !(perl_num(bst) < p.bits);
 		};
 		for (uint32_t L = 0; L <= max_len; L++) {

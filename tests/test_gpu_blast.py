@@ -354,6 +354,70 @@ def test_ungapped_flag_gives_spec_v1(pg, workload, oracle_bin, tmp_path):
     assert _capi.blast_search(db, reads).format(db, reads) == v1
     db.set_ungapped(False)
     assert _capi.blast_search(db, reads).format(db, reads) == open(workload / "oracle.tsv", "rb").read()
+    # the e-value / bit-score columns follow the TABLE: a table of a gapped search formatted after the handle was switched
+    # to -ungapped (and the other way round) keeps its own statistics
+    v2_hits = _capi.blast_search(db, reads)
+    db.set_ungapped(True)
+    assert v2_hits.format(db, reads) == open(workload / "oracle.tsv", "rb").read()
+    v1_hits = _capi.blast_search(db, reads)
+    db.set_ungapped(False)
+    assert v1_hits.format(db, reads) == v1
+    ev, bs = _capi.blast_score_columns(28, 150, 10**9, 666667)
+    evu, bsu = _capi.blast_score_columns(28, 150, 10**9, 666667, gapped=False)
+    assert bs == bsu and ev != evu     # (the length adjustment differs, the bit score does not)
+
+
+def test_dust_inside_every_search_gives_the_same_table(pg, workload):
+    """pgx_db_set_dust_each_search: S3d computed again by the search itself, on its stream, without a host wait -- the same bits,
+    the same table, and the stage shows up in the stage times.  Low-complexity reads among the ordinary ones."""
+    from pangea_plus_amd import _capi
+    import random
+    rng = random.Random(5)
+    text = open(workload / "reads.fa").read().split(">")[1:201]
+    recs = []
+    for i, rec in enumerate(text):
+        name, seq = rec.split("\n", 1)
+        seq = seq.replace("\n", "")
+        if i % 5 == 0:
+            p_ = rng.randrange(10, 100)
+            seq = seq[:p_] + rng.choice(["A" * 20, "AC" * 12, "GAT" * 9]) + seq[p_ + 24:]
+        recs.append(">%s\n%s\n" % (name, seq))
+    fa = workload / "dusty.fa"
+    fa.write_text("".join(recs))
+    db = pg.Db.from_fasta(str(workload / "db.fa"))
+    reads = pg.Reads.from_fasta(str(fa))
+    want = _capi.blast_search(db, reads).format(db, reads)
+    assert _capi.stage_times().dust_ms == 0
+    db.set_dust_each_search(True)
+    for _ in range(2):
+        assert _capi.blast_search(db, reads).format(db, reads) == want
+        assert _capi.stage_times().dust_ms > 0
+    db.set_dust(False)
+    nodust = _capi.blast_search(db, reads).format(db, reads)
+    assert _capi.stage_times().dust_ms == 0 and nodust != want      # (-dust no: more seeds, and no masking stage)
+
+
+def test_issue_probe_reports_a_rate(pg):
+    """pgx_probe_issue (the measured instruction roof bench.py quotes beside the gapped stage): every kind runs and reports a
+    plausible rate; two-operand adds issue faster than three-operand maxima."""
+    import ctypes as C
+    L = pg.lib()
+    L.pgx_probe_issue_name.restype = C.c_char_p
+    names = []
+    k = 0
+    while L.pgx_probe_issue_name(k):
+        names.append(L.pgx_probe_issue_name(k).decode())
+        k += 1
+    assert names[0] == "v_add_u32" and names[1] == "v_max3_i32" and len(names) > 20
+    rate = {}
+    for kind in (0, 1):
+        out = (C.c_double * 4)()
+        assert L.pgx_probe_issue(4, kind, out) == 0
+        rate[kind] = out[0]
+        assert 1e8 < out[0] < 3e9
+    assert rate[0] > 1.3 * rate[1]
+    out = (C.c_double * 4)()
+    assert L.pgx_probe_issue(1, 0, out) == 0 and 1e9 < out[3] < 3e9     # the shader clock, from a lone wavefront per SIMD
 
 
 @pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_INDEL_SEEDS", "5,6").split(",")])
@@ -674,3 +738,42 @@ def test_reads_of_350_to_500_bases_with_19_to_40_differences_a_side(pg, oracle_b
     assert len(rows) > 5000 and max(int(r.split(b"\t")[4]) for r in rows) >= 38   # mismatches of a row: both sides deep
     assert _blast_text(pg, db, rd, tmp_path, "tier2") == want.read_bytes()
     assert _capi.stage_times().gapped_wide > 1000   # the first tier listed them
+
+
+def test_long_queries_that_overhang_the_first_and_the_last_subject(pg, oracle_bin, tmp_path):
+    """1 500-base queries whose only match is a short subject at the very start / the very end of the database: the window of
+    letters the wide gapped kernel stages (read length + 2 x 62 + 64 letters around the anchor) would begin ~1 400 letters
+    before the packed words, or end that far behind them -- more than their 768 letters of padding (gapped.hip
+    staged such windows; those HSPs now read their letters in memory).  Both strands, both ends."""
+    import random
+    rng = random.Random(77)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))  # noqa: E731
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))  # noqa: E731
+    first, last = rnd(90), rnd(90)
+    middle = [rnd(rng.choice([300, 700, 1600])) for _ in range(40)]
+    seqs = [first] + middle + [last]
+    db = tmp_path / "ends.fa"
+    db.write_text("".join(">gi|%d|x|e%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(seqs)))
+    def with_errors(s):
+        w = list(s)
+        w[30] = comp[w[30]]              # a substitution
+        del w[55]                        # and a deletion: both sides of the anchor do gapped work
+        return "".join(w)
+    reads = [
+        rnd(1410) + with_errors(first),        # the match is the query's tail, on the first subject: window starts far in front
+        with_errors(last) + rnd(1410),         # the match is the query's head, on the last subject: window ends far behind
+        rc(rnd(1410) + with_errors(last)),     # the same on the other strand
+        rc(with_errors(first) + rnd(1410)),
+        middle[3][100:250],                    # and ordinary reads beside them
+        rc(middle[7][0:150]),
+    ]
+    rd = tmp_path / "ends_reads.fa"
+    rd.write_text("".join(">o%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+    want = tmp_path / "ends_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want), "-num_threads", "4"],
+                   timeout=600)[0] == 0
+    rows = want.read_text().splitlines()
+    assert {r.split("\t")[0] for r in rows} >= {"o0", "o1", "o2", "o3", "o4", "o5"}
+    assert any(r.split("\t")[5] != "0" for r in rows if r.startswith(("o0", "o1", "o2", "o3")))  # gapped rows among them
+    assert _blast_text(pg, db, rd, tmp_path, "ends") == want.read_bytes()
