@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--inclusive-sample", type=int, default=2_000_000, help="reads of the file-to-file line (0: skip it)")
     ap.add_argument("--n-seq", type=int, default=666667)
     ap.add_argument("--ungapped", action="store_true", help="blastn -ungapped: stop after the ungapped stage (spec v1, round 1's tables)")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="set-up only: build / broadcast / import the database, print one line per rank (device, free HBM, broadcast and "
+                         "rebuild seconds, database checksums) and fail with the rank's number if a rank's copy differs; no timed steps")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -192,11 +195,20 @@ def main():
     if args.n_seq != cfg.n_seq:  # smaller database for quick functional runs
         cfg.n_genus = max(1, cfg.n_genus * args.n_seq // cfg.n_seq)
         cfg.n_seq = args.n_seq
-    tmp = tempfile.mkdtemp(prefix="pgx_bench_%d_" % rank)
+    # one taxonomy directory per job: rank 0 writes the dumps and builds the .bin files (tax_class -c), the others open
+    # them after a barrier -- eight ranks each building the same tables was eight times the host work for nothing
+    tmp = tempfile.mkdtemp(prefix="pgx_bench_") if rank == 0 else None
+    if world > 1:
+        box = [tmp]
+        dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
     try:
         # ---- setup (untimed): taxonomy, database + seed index, one-off broadcast, binding, batches
-        _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), tmp.encode()))
-        pg.TaxDb.create(tmp)
+        if rank == 0:
+            _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), tmp.encode()))
+            pg.TaxDb.create(tmp)
+        if world > 1:
+            dist.barrier()
         tax = pg.TaxDb.open(tmp)
         t0 = time.time()
         if rank == 0:
@@ -228,6 +240,36 @@ def main():
             tt = torch.tensor([t_bcast, t_fin[0]], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_bcast, t_rebuild = float(tt[0].item()), float(tt[1].item())
+        if args.dry_ranks:
+            # what the first multi-GPU run should be: every rank reports its device and its copy of the database
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            mine = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank), "hbm_free_GiB": free_b / 2**30,
+                    "hbm_total_GiB": total_b / 2**30, "broadcast_s": t_bcast, "index_rebuild_s": t_rebuild, "checksum": list(db.checksum())}
+            bad = 0
+            if world > 1:
+                # checksums as two halves (the sums are 64-bit; the collective is on int64 tensors)
+                cs = torch.tensor([x & 0x7FFFFFFF for x in mine["checksum"]] + [x >> 31 for x in mine["checksum"]], dtype=torch.int64, device=dev)
+                rank0 = cs.clone()
+                dist.broadcast(rank0, src=0)
+                bad = int(not torch.equal(cs, rank0))
+                rows = [None] * world
+                dist.all_gather_object(rows, mine)
+                flag = torch.tensor([bad], dtype=torch.int64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+                n_bad = int(flag.item())
+            else:
+                rows, n_bad = [mine], 0
+            if rank == 0:
+                for r in rows:
+                    print(json.dumps(r), flush=True)
+                print(json.dumps({"dry_ranks": world, "ranks_that_differ_from_rank_0": n_bad,
+                                  "ranks": [r["rank"] for r in rows if r["checksum"] != rows[0]["checksum"]]}), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            if bad:
+                sys.exit("bench.py --dry-ranks: rank %d holds a different database than rank 0" % rank)
+            return
         db.bind_taxonomy(tax)
         if args.ungapped:
             db.set_ungapped(True)
@@ -388,7 +430,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

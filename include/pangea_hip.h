@@ -78,6 +78,11 @@ typedef struct {
 int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out);
 int pgx_db_alloc_like(const pgx_db_shape *shape, pgx_db **out);
 int pgx_db_finish_import(pgx_db *db);
+/* Sums over the database as it stands in THIS GPU's memory, for ranks to compare after the one broadcast of a multi-GPU
+ * run (the launcher this stands in for: reference Scripts/submit_MPI-blast.job:24; bench.py --dry-ranks): out[0] = sum of
+ * the packed base words, out[1] = sum of the sequence offsets, out[2] = sum of the seed index's bucket offsets, out[3] = sum of
+ * its postings -- each a wrapping 64-bit sum of the array's elements, computed on the device. */
+int pgx_db_checksum(pgx_db *db, uint64_t out[4]);
 
 /* ------------------------------------------------------------------------------------------
  * Classify, BLAST verb  —  `blastn -query F -db DB -outfmt 6 -out O` (README.md:96;

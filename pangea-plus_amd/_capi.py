@@ -87,7 +87,7 @@ VOTE_DTYPE = np.dtype([("depth", "<i4"), ("name", "<u4", (7,)), ("votes", "u1", 
 SYMBOLS = [
     "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_db_build", "pgx_db_open",
     "pgx_db_from_fasta", "pgx_db_close", "pgx_db_num_seqs", "pgx_db_num_bases", "pgx_db_seq_id",
-    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust", "pgx_db_set_dust_each_search",
+    "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_db_checksum", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust", "pgx_db_set_dust_each_search",
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",
     "pgx_tax_node", "pgx_tax_names", "pgx_tax_format_node", "pgx_tax_format_name", "pgx_tax_cli", "pgx_free",
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
@@ -262,6 +262,12 @@ class Db(_Handle):
         s = _DbShape()
         _check(lib().pgx_db_get_shape(self.ptr, C.byref(s)))
         return (s.n_seq, s.n_bases, s.has_amb, s.index_bits, s.n_postings, s.synthetic_ids)
+
+    def checksum(self):
+        """wrapping 64-bit sums of (packed bases, sequence offsets, bucket offsets, postings) as they stand on this GPU"""
+        out = (C.c_uint64 * 4)()
+        _check(lib().pgx_db_checksum(self.ptr, out))
+        return tuple(int(x) for x in out)
 
     def device_arrays(self):
         arr = (_DevArray * 16)()

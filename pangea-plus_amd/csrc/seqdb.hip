@@ -1438,6 +1438,19 @@ std::string pgx_reads::name_of(int64_t i) const
 	return h_text->substr(name_off[(size_t)i], name_len[(size_t)i]);
 }
 
+namespace pgx {
+template <typename T> __global__ __launch_bounds__(256) void k_wrapping_sum(const T *__restrict__ a, uint64_t n, unsigned long long *__restrict__ out)
+{
+	unsigned long long acc = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		acc += (unsigned long long)a[i];
+	for (int sh = 32; sh >= 1; sh >>= 1)
+		acc += __shfl_xor(acc, sh);
+	if ((threadIdx.x & 63) == 0)
+		atomicAdd(out, acc);
+}
+} // namespace pgx
+
 using namespace pgx;
 
 extern "C" {
@@ -1724,6 +1737,33 @@ int pgx_db_device_arrays(pgx_db *db, pgx_device_array *out, int cap)
 		add("post_ctx", db->d_post_ctx.data(), db->d_post_ctx.bytes());
 	}
 	return n;
+}
+
+int pgx_db_checksum(pgx_db *db, uint64_t out[4])
+{
+	if (!db || !out)
+		return fail(PGX_E_ARG, "pgx_db_checksum: null argument");
+	PGX_TRY(require_device());
+	return guard("pgx_db_checksum", [&]() -> int {
+		DevBuf<unsigned long long> d;
+		PGX_TRY(d.alloc(4, 0, 0, true));
+		const unsigned grid = 256 * 8;
+		if (db->d_words.n)
+			hipLaunchKernelGGL(k_wrapping_sum<uint64_t>, dim3(grid), dim3(256), 0, 0, db->d_words.data(), (uint64_t)db->d_words.n, d.data() + 0);
+		if (db->d_seq_off.n)
+			hipLaunchKernelGGL(k_wrapping_sum<uint32_t>, dim3(grid), dim3(256), 0, 0, db->d_seq_off.data(), (uint64_t)db->n_seq + 1, d.data() + 1);
+		if (db->d_bucket_off.base && db->index_bits > 0)
+			hipLaunchKernelGGL(k_wrapping_sum<uint32_t>, dim3(grid), dim3(256), 0, 0, db->d_bucket_off.data(), ((uint64_t)1 << db->index_bits) + 1,
+					   d.data() + 2);
+		if (db->d_postings.base && db->n_postings > 0)
+			hipLaunchKernelGGL(k_wrapping_sum<uint32_t>, dim3(grid), dim3(256), 0, 0, db->d_postings.data(), (uint64_t)db->n_postings, d.data() + 3);
+		PGX_HIP(hipGetLastError());
+		unsigned long long h[4];
+		PGX_TRY(d.download(h, 4));
+		for (int i = 0; i < 4; i++)
+			out[i] = h[i];
+		return 0;
+	});
 }
 
 int pgx_db_alloc_like(const pgx_db_shape *s, pgx_db **out)

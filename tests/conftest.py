@@ -21,7 +21,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle_bin():
-    """The CPU restatement (test infrastructure). Built on demand with plain make."""
+    """The CPU restatement (test infrastructure). Built on demand with plain make.  PGX_ORACLE_SAN=1: the build under
+    AddressSanitizer + UndefinedBehaviorSanitizer (`make -C oracle san`), every report fatal."""
+    if os.environ.get("PGX_ORACLE_SAN", "0") not in ("", "0"):
+        san = os.path.join(ORACLE_DIR, "bin", "pgx_oracle_san")
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "san"], stdout=subprocess.DEVNULL)
+        os.environ.setdefault("ASAN_OPTIONS", "abort_on_error=1:detect_leaks=0")
+        os.environ.setdefault("UBSAN_OPTIONS", "halt_on_error=1:print_stacktrace=1")
+        return san
     if not os.path.exists(ORACLE_BIN) or not os.path.exists(os.path.join(ORACLE_DIR, "liboracle.so")):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so", "bin/pgx_oracle"],
                               stdout=subprocess.DEVNULL)

@@ -50,3 +50,20 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
     assert j["setup_s"]["index_broadcast_bytes"] > 0
     assert j["setup_s"]["broadcast_mode"].startswith("packed bases")
+
+
+def test_dry_ranks_reports_every_rank_and_compares_the_database_copies():
+    """`bench.py --gpus 2 --dry-ranks`: what the first multi-GPU run should be (the `mpirun -np N` of the reference's
+    Scripts/submit_MPI-blast.job:24): set-up only, one line per rank -- device, free HBM, broadcast and rebuild seconds, sums
+    over the database as it stands on that GPU -- and a verdict; the receiving rank rebuilt its seed index itself, so equal
+    sums mean the broadcast AND the local rebuild gave rank 0's index."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "--n-seq", "20000"]
+    p = subprocess.run(cmd, env=_env(PGX_BENCH_ONE_DEVICE="1", PGX_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 3, p.stdout
+    r0, r1, verdict = lines
+    assert (r0["rank"], r1["rank"]) == (0, 1) and r0["checksum"] == r1["checksum"] and all(x > 0 for x in r0["checksum"])
+    assert r1["index_rebuild_s"] > 0 and r0["hbm_free_GiB"] > 1
+    assert verdict == {"dry_ranks": 2, "ranks_that_differ_from_rank_0": 0, "ranks": []}
