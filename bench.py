@@ -344,7 +344,7 @@ def main():
             if os.path.exists(tp):
                 try:
                     tj = json.load(open(tp))
-                    traffic, gap_traffic = tj.get("k_seed_extend_bytes_per_launch"), tj.get("k_gapped_fast_bytes_per_launch")
+                    traffic, gap_traffic = tj.get("k_seed_extend_bytes_per_launch"), tj.get("k_gapped_stage_bytes_per_launch")
                     if not (B == 10_000_000 and args.n_seq == pg.SynthCfg.default().n_seq):
                         traffic = gap_traffic = None  # the counter figures are for the default launch only
                 except Exception:
@@ -394,26 +394,48 @@ def main():
                          "kernel_ms_per_launch": kernel_ms / args.steps,
                          "survey_8d": survey_8d(last.hits / B, world * B * args.steps / dt / world), "random_line_roof": line_roof}
             if gap_ms > kernel_ms:
-                # spec v2: the gapped stage is the longest kernel of the step.  It is integer work on letters held in LDS and
-                # registers (no MFMA; ~45 vector instructions per cell of the greedy recurrence), so its share of the HBM
-                # roof is small by nature; the line says so instead of hiding the kernel behind the seed stage's.  What
-                # bounds it is instruction issue: `issue` = vector instructions per launch (PMC, profiles/) x 4 cycles /
-                # (1024 SIMDs x the launch's cycles at 2.4 GHz), scaled from the PMC run's 1 M reads to this launch
+                # spec v2: the gapped stage is the longest stage of the step (k_gapped_rows + its counting sorts + the list
+                # tiers).  It is integer work on letters held in LDS and registers (no MFMA), so its share of the streaming
+                # HBM roof is small by nature; the line says so instead of hiding the stage behind the seed stage's.  What
+                # bounds it, both measured in this run: (1) random 64-byte lines per second -- every HSP's record, read strand
+                # and result are single-use lines (the database words stay in L2 because the HSPs are handled region by
+                # region); (2) vector instructions per second per SIMD (pgx_probe_issue: two-operand adds / ands / shifts
+                # issue about twice as fast as everything else on this chip).
                 g_ach = gap_bytes / (gap_ms * 1e-3) / 1e9
+                tj = {}
+                try:
+                    tj = json.load(open(tp))
+                except Exception:
+                    pass
+                full = B == 10_000_000 and args.n_seq == pg.SynthCfg.default().n_seq
+                lines_roof = None
+                try:
+                    if line_roof and "roof_lines_per_s" in line_roof and tj.get("k_gapped_rows_l2_misses_per_read") and full:
+                        miss = tj["k_gapped_rows_l2_misses_per_read"] * B * args.steps / (tj.get("k_gapped_rows_share_of_stage", 1.0) * gap_ms * 1e-3)
+                        lines_roof = {"roof_lines_per_s": line_roof["roof_lines_per_s"], "kernel_l2_misses_per_s": miss,
+                                      "frac": miss / line_roof["roof_lines_per_s"],
+                                      "basis": "TCC_MISS of k_gapped_rows per read (profiles/traffic.json: %.1f) x reads / the kernel's share of the stage time, against pgx_probe_gather" % tj["k_gapped_rows_l2_misses_per_read"]}
+                except Exception:
+                    lines_roof = None
                 issue = None
                 try:
-                    valu_per_read = json.load(open(tp)).get("k_gapped_fast_valu_instructions_per_read")
-                    if valu_per_read:
-                        busy = valu_per_read * B * 4.0 / (1024 * 2.4e9 * (gap_ms / args.steps) * 1e-3)
-                        issue = {"valu_instructions_per_read": valu_per_read, "valu_busy_frac_at_2.4GHz": busy,
-                                 "basis": "SQ_INSTS_VALU of k_gapped_fast per read (profiles/r02_gapped_instruction_mix.txt) x reads x 4 cycles / (1024 SIMDs x kernel time)"}
-                except Exception:
-                    issue = None
-                out["roofline"] = {"bound": "hbm", "kernel": "k_gapped_fast (+ k_gapped_big)", "achieved": g_ach, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": gap_traffic,
+                    fast, slow = (C.c_double * 4)(), (C.c_double * 4)()
+                    _capi._check(pg.lib().pgx_probe_issue(4, 0, fast))   # v_add_u32: the two-operand kind
+                    _capi._check(pg.lib().pgx_probe_issue(4, 1, slow))   # v_max3_i32: every other kind
+                    valu_per_read = tj.get("k_gapped_rows_valu_instructions_per_read")
+                    issue = {"roof_fast_kind_per_s_per_simd": fast[0], "roof_other_kinds_per_s_per_simd": slow[0]}
+                    if valu_per_read and full:
+                        per_s_per_simd = valu_per_read * B * args.steps / (tj.get("k_gapped_rows_share_of_stage", 1.0) * gap_ms * 1e-3) / 1024
+                        issue.update({"valu_instructions_per_read": valu_per_read, "kernel_valu_per_s_per_simd": per_s_per_simd,
+                                      "busy_if_all_fast": per_s_per_simd / fast[0], "busy_if_all_other": per_s_per_simd / slow[0],
+                                      "basis": "SQ_INSTS_VALU of k_gapped_rows per read (profiles/) x reads / (1024 SIMDs x kernel time), against the measured issue rates of the two kinds of vector instruction at 4 wavefronts per SIMD"})
+                except Exception as e:
+                    issue = {"error": str(e)}
+                out["roofline"] = {"bound": "hbm", "kernel": "k_gapped_rows (+ k_reg_* / k_seg_* sorting passes, list tiers)", "achieved": g_ach,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": gap_traffic,
                                    "alg_bytes_per_launch": gap_bytes / args.steps, "kernel_ms_per_launch": gap_ms / args.steps,
-                                   "note": "bound by instruction issue, not by memory: see DESIGN.md section 7", "issue": issue,
-                                   "seed_extend": seed_roof}
+                                   "note": "the stage's real roofs are the random-line rate and the issue rate, both measured here: see DESIGN.md sections 6-7",
+                                   "random_line_roof": lines_roof, "issue": issue, "seed_extend": seed_roof}
             else:
                 out["roofline"] = seed_roof
             if world == 1 and args.inclusive_sample > 0 and not args.no_cpu_baseline:

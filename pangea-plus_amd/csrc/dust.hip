@@ -63,11 +63,13 @@ __device__ __forceinline__ void dust_wave_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
-struct TrigLane {
-	uint8_t cw[64], cv[64], ct[64];
-	uint32_t pad; // 49 words per lane: an even word stride put the 64 lanes' counters on two LDS banks (32-way conflicts)
+// (the first pass never walks the longer suffixes: without `ct` its wavefront needs 8.4 KB of LDS instead of 12.5 -- 4 to a
+// SIMD instead of 3 for a kernel that waits on its own LDS counters)
+template <bool CONFIRM> struct TrigLaneT {
+	uint8_t cw[64], cv[64], ct[CONFIRM ? 64 : 4];
+	uint32_t pad[CONFIRM ? 1 : 2]; // an odd word stride per lane: an even one put the 64 lanes' counters on two LDS banks (32-way conflicts)
 };
-static_assert(sizeof(TrigLane) / 4 % 2 == 1, "odd word stride");
+static_assert(sizeof(TrigLaneT<true>) / 4 % 2 == 1 && sizeof(TrigLaneT<false>) / 4 % 2 == 1, "odd word stride");
 
 // the trigger works on raw 6-bit triplet codes (any one-to-one naming of the 64 triplets counts the same pairs)
 __device__ __forceinline__ int dust_tid(const uint64_t *rw, const uint64_t *ra, int i)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 						      const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ n_in,
 						      uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
 {
+	using TrigLane = TrigLaneT<CONFIRM>;
 	__shared__ TrigLane s_lane[64];
 	__shared__ uint32_t s_hist[64];
 	TrigLane &ld = s_lane[threadIdx.x];
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			first = first < 0 ? b : first;
 			last = b;
 		}
-		if (CONFIRM && t >= 0 && rw_pairs * 10 > L * kDustLevel) {
+		if constexpr (CONFIRM) {
+		if (t >= 0 && rw_pairs * 10 > L * kDustLevel) {
 			// the algorithm would now look at the suffixes LONGER than that suffix, longest last; an interval that scores
 			// above the level exists in the read exactly when one of these does somewhere (its best sub-interval is
 			// perfect), so this decides whether the read has a masked base at all
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 					break;
 				}
 			}
+		}
 		}
 	}
 	// one atomic per wavefront (a single counter takes ~90 M atomics a second: one per listed read was most of this kernel)

@@ -149,6 +149,15 @@ def test_config5_third_stream_is_opened_and_ignored(pg, oracle_bin, tmp_path):
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c2.txt"))
     pg.consensus(str(tmp_path / "hits_class.tsv"), str(tmp_path / "rdp.tsv"), str(tmp_path / "c3.txt"), s=str(tmp_path / "soap.txt"))
     assert (tmp_path / "c2.txt").read_bytes() == (tmp_path / "c3.txt").read_bytes() == _capi.consensus_format(db, reads, h2, r2)
+    # and the checker's chain, with the third stream given to its consensus verb as well (not product against product):
+    # oracle blastn -> oracle taxcollector -> oracle consensus -b -r -s, the restatement the reference Perl pins (goldens)
+    assert run_cmd([oracle_bin, "blastn", "-query", str(tmp_path / "reads.fa"), "-db", str(tmp_path / "db.fa"), "-outfmt", "6", "-out",
+                    str(tmp_path / "o_hits.tsv"), "-num_threads", "8"], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "taxcollector", "-f", str(tmp_path / "o_hits.tsv"), "-o", str(tmp_path / "o_class.tsv"), "-d",
+                    str(tmp_path / "Tax_class")], timeout=600)[0] == 0
+    assert run_cmd([oracle_bin, "consensus", "-b", str(tmp_path / "o_class.tsv"), "-r", str(tmp_path / "rdp.tsv"), "-s", str(tmp_path / "soap.txt"),
+                    "-o", str(tmp_path / "o_c3.txt")], timeout=600)[0] == 0
+    assert (tmp_path / "o_c3.txt").read_bytes() == (tmp_path / "c3.txt").read_bytes()
 
 
 def test_config5_opt_in_three_way_vote(pg, oracle_bin, tmp_path):
