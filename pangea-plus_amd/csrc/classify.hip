@@ -2099,12 +2099,13 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		PGX_HIP(hipMemcpyAsync(h_cnt, ws.counters.data(), kNCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		h_cnt[kNCounters] = 0;
 		if (dv.gapped)
-			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters, ws.gapped.big_count.data(), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters, ws.gapped.big_count.data(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st)); // lists A and B
 		PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 1, out->d_read_off.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		PGX_HIP(hipStreamSynchronize(st));
 		H_ovf = h_cnt[4];
 		H = h_cnt[5] + H_ovf;
-		const uint64_t gap_listed = (uint32_t)h_cnt[kNCounters], gap_cap = ws.gapped.big_list.n;
+		// (either list of the gapped stage's first tier may have outgrown its buffer: both have the capacity of list A's)
+		const uint64_t gap_listed = std::max<uint64_t>((uint32_t)h_cnt[kNCounters], (uint32_t)(h_cnt[kNCounters] >> 32)), gap_cap = ws.gapped.big_list.n;
 		bool again = false;
 		if (h_cnt[0] > cap) {
 			cap = h_cnt[0] + h_cnt[0] / 8;
@@ -2136,7 +2137,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	tm.postings = (int64_t)h_cnt[2];
 	tm.candidates = (int64_t)h_cnt[3];
 	tm.survivors = (int64_t)h_cnt[6];
-	tm.gapped_wide = (int64_t)(uint32_t)h_cnt[kNCounters];
+	tm.gapped_wide = (int64_t)(uint32_t)h_cnt[kNCounters] + (int64_t)(uint32_t)(h_cnt[kNCounters] >> 32);
 	tm.seed_extend_ms = ws.ev.ms(0, 1);
 	tm.gapped_ms = ws.ev.ms(1, 2);
 	tm.group_ms = ws.ev.ms(2, 3);

@@ -1262,12 +1262,25 @@ template <int MAXL> struct RowsLds {
 	uint32_t seq[kRows * 64];
 };
 
+// Where the lean tier hands on what it cannot finish: list A = HSPs whose best cell holds two gap columns of a kind (the
+// rows with the full statistics over 18 differences decide them), list B = HSPs alive after 18 differences, HSPs the seed
+// stage's own estimate puts beyond 18 levels, HSPs that touch an ambiguity letter (the 40-difference tier and the wide
+// kernels: sending them through list A's tier first ran reads of 400-500 bases 10-15 % slower than round 2).
+struct TierLists {
+	unsigned long long *a, *b;
+	uint32_t *a_count, *b_count;
+	uint32_t cap;
+};
+struct Pending {
+	uint32_t na = 0, nb = 0; // table slots waiting in front row 0 (for list A) and front row 1 (for list B), <= 64 each
+};
+
 // One round of 64 HSPs, one per lane, both sides: the record once, the letters once (right part forward, left part
 // reversed, packed behind one another in the lane's column of the transposed rows), the lean rows left then right, the
 // finished hit over the record.  HSPs this tier cannot finish wait in the two front rows (`n_pend` table slots).
 template <int MAXL>
-__device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, pgx_hit *__restrict__ table, pgx_hit *hp, bool mine, uint32_t &n_pend,
-					  unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap)
+__device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, pgx_hit *__restrict__ table, pgx_hit *hp, bool mine, Pending &pend,
+					  const TierLists &tl)
 {
 	using Lds = RowsLds<MAXL>;
 	constexpr int D = kGFastD;
@@ -1277,6 +1290,9 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, 
 	const pgx_hit h = *hp;
 	const Anchor a = anchor_of(v, h);
 	bool on = mine && a.L <= MAXL;
+	// (the seed stage's own estimate of the levels a side will run, floor((2 letters - B0) / 5): a side it puts two levels
+	// beyond this tier's D would run all D levels here only to be handed on)
+	on = on && (2 * a.qa - a.b0l) / 5 <= D + 1 && (2 * (a.L - a.qa) - a.b0r) / 5 <= D + 1;
 	if (on && a.s.ra) {
 		uint64_t any = 0;
 		for (int w = 0; w < (a.L + 31) / 32; w++)
@@ -1341,65 +1357,91 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, 
 		}
 	}
 	lds_sync();
-	Side sd[2];
-	bool ok = true;
+	// What has to outlive the rows is kept SMALL and packed: in this kernel a spilled register is memory traffic (136 bytes
+	// of scratch per lane were ~1.3 of the 4.6 L2 misses per HSP).  Slot number, anchor | length, the record's `send` word
+	// (strand | B0 left | B0 right), the anchor's place in the subject and the subject's length, the two sides' bit offsets,
+	// the left side's result in two words.  `read` and `subject` of the record stay where they are: the hit is written
+	// over the other 24 bytes.
+	const uint32_t slot = (uint32_t)(hp - table);
+	const uint32_t geo = (uint32_t)a.qa | ((uint32_t)a.L << 10), send_w = (uint32_t)h.send;
+	const int sa = a.sa, slen = a.slen;
+	const uint32_t off_l = (uint32_t)QB[0] | ((uint32_t)DB0[0] << 16), off_r = (uint32_t)QB[1] | ((uint32_t)DB0[1] << 16);
+	uint32_t left_pk = 0;
+	int left_s2 = 0;
+	Side rr;
+	rr.i = rr.j = rr.s2 = rr.mism = rr.gopen = 0;
+	int worst = 0; // 0 both sides done, 2 a side needs the full statistics, 1 a side is alive after D differences
 #pragma unroll 1
 	for (int side = 0; side < 2; side++) {
+		const int qa_ = (int)(geo & 1023u), L_ = (int)(geo >> 10);
+		const uint32_t off = side ? off_r : off_l;
 		Side r;
-		const int st = greedy_rows_lean<D>(seq0, (uint32_t)lane * 4u, on, side ? QB[1] : QB[0], side ? DB0[1] : DB0[0], side ? a.L - a.qa : a.qa,
-						   side ? a.slen - a.sa : a.sa, side ? a.b0r : a.b0l, r);
-		ok = ok && st == 0;
-		if (side)
-			sd[1] = r;
-		else
-			sd[0] = r;
-	}
-	if (on && ok)
-		write_gapped(hp, h, a, sd[0], sd[1]);
-	const bool fail = mine && !(on && ok);
-	const unsigned long long fm = __ballot(fail);
-	lds_sync(); // (the rows' reads are done before the letters are replaced)
-	if (fm != 0ull) {
-		if (fail)
-			lds.seq[n_pend + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)(hp - table);
-		n_pend += (uint32_t)__popcll(fm);
-		lds_sync();
-		if (n_pend > 64u) {
-			for (uint32_t e0 = 0; e0 < n_pend; e0 += 64) {
-				const bool m2 = e0 + lane < n_pend;
-				list_append(m2, table + (m2 ? lds.seq[e0 + lane] : 0u), big_list, big_count, big_cap);
-			}
-			n_pend = 0;
-			lds_sync();
+		const int st = greedy_rows_lean<D>(seq0, (uint32_t)lane * 4u, on, (int)(off & 0xFFFFu), (int)(off >> 16), side ? L_ - qa_ : qa_,
+						   side ? slen - sa : sa, (int)(side ? (send_w >> 12) & 0x7FFu : (send_w >> 1) & 0x7FFu), r);
+		worst = st == 1 || worst == 1 ? 1 : (st == 2 || worst == 2 ? 2 : 0);
+		if (side) {
+			rr = r;
+		} else {
+			left_pk = (uint32_t)r.i | ((uint32_t)r.j << 10) | ((uint32_t)r.mism << 20) | ((uint32_t)r.gopen << 26);
+			left_s2 = r.s2;
 		}
 	}
+	if (on && worst == 0) {
+		const int qa_ = (int)(geo & 1023u), L_ = (int)(geo >> 10);
+		const int li = (int)(left_pk & 1023u), lj = (int)((left_pk >> 10) & 1023u);
+		const int bl = qa_ - li, br = qa_ + rr.i - 1, sl = sa - lj, sr = sa + rr.j - 1;
+		int4 c; // qstart, qend, sstart, send
+		if (!(send_w & 1u))
+			c = make_int4(bl + 1, br + 1, sl + 1, sr + 1);
+		else
+			c = make_int4(L_ - br, L_ - bl, sr + 1, sl + 1);
+		pgx_hit *dst = table + slot;
+		*reinterpret_cast<int4 *>(&dst->qstart) = c;
+		const uint32_t mg = ((left_pk >> 20) & 63u) + (uint32_t)rr.mism + ((((left_pk >> 26) & 63u) + (uint32_t)rr.gopen) << 16);
+		*reinterpret_cast<int2 *>(&dst->score) = make_int2((left_s2 + rr.s2) >> 1, (int)mg);
+	}
+	const bool fail_a = mine && on && worst == 2, fail_b = mine && (!on || worst == 1);
+	lds_sync(); // (the rows' reads are done before the letters are replaced)
+	auto park = [&](bool fail, uint32_t &n, int row, unsigned long long *list, uint32_t *count) {
+		const unsigned long long fm = __ballot(fail);
+		if (fm == 0ull)
+			return;
+		const uint32_t cnt = (uint32_t)__popcll(fm);
+		if (n + cnt > 64u) { // the row is full: its slots go to the list, one atomic for all of them
+			list_append(lane < (int)n, table + (lane < (int)n ? lds.seq[row * 64 + lane] : 0u), list, count, tl.cap);
+			n = 0;
+			lds_sync();
+		}
+		if (fail)
+			lds.seq[row * 64 + n + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = slot;
+		n += cnt;
+		lds_sync();
+	};
+	park(fail_a, pend.na, 0, tl.a, tl.a_count);
+	park(fail_b, pend.nb, 1, tl.b, tl.b_count);
 }
 
 template <int MAXL>
-__device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restrict__ table, uint32_t &n_pend, unsigned long long *__restrict__ big_list,
-					  uint32_t *__restrict__ big_count, uint32_t big_cap)
+__device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restrict__ table, Pending &pend, const TierLists &tl)
 {
 	const int lane = threadIdx.x & 63;
-	for (uint32_t e0 = 0; e0 < n_pend; e0 += 64) {
-		const bool m2 = e0 + lane < n_pend;
-		list_append(m2, table + (m2 ? lds.seq[e0 + lane] : 0u), big_list, big_count, big_cap);
-	}
-	n_pend = 0;
+	list_append(lane < (int)pend.na, table + (lane < (int)pend.na ? lds.seq[lane] : 0u), tl.a, tl.a_count, tl.cap);
+	list_append(lane < (int)pend.nb, table + (lane < (int)pend.nb ? lds.seq[64 + lane] : 0u), tl.b, tl.b_count, tl.cap);
+	pend.na = pend.nb = 0;
 	lds_sync();
 }
 
-// the binned form (PGX_GAP_BINS=1): rounds of 64 consecutive entries of the binned slot list
+// the main table: rounds of 64 consecutive entries of the sorted slot list
 template <int MAXL, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_rows(GapView v, pgx_hit *__restrict__ table, const uint32_t *__restrict__ items,
-													  uint32_t *__restrict__ bins, unsigned long long *__restrict__ big_list,
-													  uint32_t *__restrict__ big_count, uint32_t big_cap)
+													  uint32_t *__restrict__ bins, TierLists tl)
 {
 	__shared__ RowsLds<MAXL> lds;
 	const int lane = threadIdx.x & 63;
 	const uint32_t n_items = bins[kTotalAt];
 	uint32_t *next_round = bins + kTotalAt + 1; // (zero at launch)
 	const uint32_t n_rounds = (n_items + 63u) / 64u;
-	uint32_t n_pend = 0;
+	Pending pend;
 	// rounds are handed out in order, kRoundGrab at a time, from one counter: the wavefronts in flight then work on
 	// neighbouring rounds -- one or two database regions -- however unevenly they progress (with a fixed stride per
 	// wavefront they drifted tens of regions apart and the region order bought nothing)
@@ -1415,10 +1457,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 		for (uint32_t round = first; round < last; round++) {
 			const uint32_t idx = round * 64u + lane;
 			const bool mine = idx < n_items;
-			gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, n_pend, big_list, big_count, big_cap);
+			gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, pend, tl);
 		}
 	}
-	gap_flush<MAXL>(lds, table, n_pend, big_list, big_count, big_cap);
+	gap_flush<MAXL>(lds, table, pend, tl);
 }
 
 // The pool form, ONE pass (round 3): a wavefront takes the HSPs of 64 reads (FLAT: 2 048 entries of the overflow table),
@@ -1432,8 +1474,7 @@ template <bool FLAT, int MAXL, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_pool(GapView v, pgx_hit *__restrict__ table, unsigned long long table_cap,
 													  const uint32_t *__restrict__ read_start, const uint32_t *__restrict__ read_cnt,
 													  uint32_t n_reads, const unsigned long long *__restrict__ flat_count,
-													  unsigned long long *__restrict__ big_list, uint32_t *__restrict__ big_count,
-													  uint32_t big_cap, uint32_t *__restrict__ order_all)
+													  TierLists tl, uint32_t *__restrict__ order_all)
 {
 	__shared__ RowsLds<MAXL> lds;
 	static_assert(RowsLds<MAXL>::kRows * 64 >= 128 + kGapBins, "the buckets borrow the letter rows");
@@ -1443,7 +1484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 	const unsigned long long n_flat_raw = FLAT ? *flat_count : 0ull;
 	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
 	const unsigned long long n_blocks = FLAT ? (n_flat + kBlkItems - 1) / kBlkItems : ((unsigned long long)n_reads + 63ull) / 64ull;
-	uint32_t n_pend = 0;
+	Pending pend;
 	for (unsigned long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
 		uint32_t excl = 0, st = 0, T;
 		if (FLAT) {
@@ -1531,10 +1572,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 			for (uint32_t it = 0; it < n_it; it += 64) {
 				const bool mine = it + lane < n_it;
 				const uint32_t item = __hip_atomic_load(&order[mine ? it + lane : n_it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				gap_round<MAXL>(lds, v, table, locate(chunk + item), mine, n_pend, big_list, big_count, big_cap);
+				gap_round<MAXL>(lds, v, table, locate(chunk + item), mine, pend, tl);
 			}
 		}
-		gap_flush<MAXL>(lds, table, n_pend, big_list, big_count, big_cap);
+		gap_flush<MAXL>(lds, table, pend, tl);
 	}
 }
 
@@ -1832,7 +1873,9 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		hipLaunchKernelGGL(k_seg_scatter, dim3(256 * 8), dim3(256), 0, stream, gw.keys1.data(), gw.items1.data(), gw.bins.data(), gw.items.data());
 	}
 	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
-	uint32_t *cnt = gw.big_count.data(); // [0] list A (checked by the caller), [1] B, [2] C (in A's buffer), [3] D (in B's)
+	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's)
+	// (long reads: every HSP goes straight to the wide kernels, which read list A)
+	const TierLists tl = { listA, long_reads ? listA : listB, cnt, long_reads ? cnt : cnt + 1, cap };
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
 	// the two tables; then the rows with the full statistics over what they listed (list A), which lists for the wider tiers (B)
 #define PGX_GAPPED_LAUNCH(ML, WV)                                                                                                              \
@@ -1841,14 +1884,14 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		const unsigned grid_wv = std::min<unsigned>(grid, 256u * 4u * WV * 2u); /* two full rounds of resident wavefronts */  \
 		if (binned)                                                                                                                  \
 			hipLaunchKernelGGL((k_gapped_rows<ML, (WV > 4 ? 4 : WV)>), dim3(256u * 4u * (WV > 4 ? 4 : WV) * 2u), dim3(64), 0, stream, v, main_table, \
-					   gw.items.data(), gw.bins.data(), listA, cnt, cap);                                                     \
+					   gw.items.data(), gw.bins.data(), tl);                                                                  \
 		else if (pools2)                                                                                                             \
 			hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
 					   read_start, read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap,  \
 					   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
 		else                                                                                                                         \
 			hipLaunchKernelGGL((k_gapped_pool<false, ML, (WV > 4 ? 4 : WV)>), dim3(std::max(1u, std::min<unsigned>(grid, 256u * 4u * (WV > 4 ? 4 : WV) * 2u))), dim3(64), 0, stream, \
-					   v, main_table, hit_cap, read_start, read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap, gw.order.data()); \
+					   v, main_table, hit_cap, read_start, read_cnt, n, (const unsigned long long *)nullptr, tl, gw.order.data()); \
 		v.key = ovf_key;                                                                                                             \
 		if (pools2)                                                                                                                  \
 			hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,          \
@@ -1856,7 +1899,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 					   cnt, cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
 		else                                                                                                                         \
 			hipLaunchKernelGGL((k_gapped_pool<true, ML, (WV > 4 ? 4 : WV)>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,       \
-					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, listA, cnt, cap, gw.order.data()); \
+					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, tl, gw.order.data()); \
 		if (!long_reads)                                                                                                             \
 			hipLaunchKernelGGL((k_gapped_fast<2, ML, WV, kGFastD>), dim3(256 * 4 * WV), dim3(64), 0, stream, v,                      \
 					   reinterpret_cast<pgx_hit *>(listA), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, \
