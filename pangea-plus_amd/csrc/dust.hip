@@ -388,6 +388,92 @@ __global__ void k_dust_windows(const uint64_t *__restrict__ mask, const uint8_t 
 	}
 }
 
+// The second trigger pass and the mask kernel run one lane per LISTED read, and a lane's work grows with the stretch of
+// positions that passed the pass before (last - first): the suffix walks there, the rows of the dynamic programme here.  A
+// wavefront runs as long as its longest lane, so the lists are ordered by that length first, longest first (a counting sort,
+// 256 buckets, order inside a bucket left open: the kernels behind treat every read on its own).  k_dust_mask: 6.1 -> see
+// DESIGN section 7.
+__global__ __launch_bounds__(256) void k_dust_order_hist(const uint2 *__restrict__ range, const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ hist)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t n = *n_ptr;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const uint2 r = range[i];
+		const uint32_t k = r.y - r.x;
+		atomicAdd(&h[k < 255u ? k : 255u], 1u);
+	}
+	__syncthreads();
+	if (h[threadIdx.x])
+		atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// hist[0 .. 255] -> hist[256 + k] = entries with a longer range than k (where bucket k starts)
+__global__ __launch_bounds__(256) void k_dust_order_bases(uint32_t *__restrict__ hist)
+{
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (int k = 255; k >= 0; k--) {
+			hist[256 + k] = run;
+			run += hist[k];
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_dust_order_scatter(const uint32_t *__restrict__ list, const uint2 *__restrict__ range,
+							    const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ hist, uint32_t *__restrict__ list_out,
+							    uint2 *__restrict__ range_out)
+{
+	// per tile of 2 048 entries: bucket counts in LDS, ONE global atomic per bucket and tile (most entries share a handful of
+	// buckets, and a single address takes ~90 M atomics a second), places inside the tile from LDS atomics
+	__shared__ uint32_t h[256], at[256];
+	const uint32_t n = *n_ptr;
+	for (uint32_t t0 = blockIdx.x * 2048u; t0 < n; t0 += gridDim.x * 2048u) {
+		h[threadIdx.x] = 0;
+		__syncthreads();
+		uint2 r[8];
+		uint32_t k[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint32_t i = t0 + q * 256u + threadIdx.x;
+			r[q] = i < n ? range[i] : make_uint2(0u, 0u);
+			k[q] = r[q].y - r[q].x;
+			k[q] = k[q] < 255u ? k[q] : 255u;
+			if (i < n)
+				atomicAdd(&h[k[q]], 1u);
+		}
+		__syncthreads();
+		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&hist[256 + threadIdx.x], h[threadIdx.x]) : 0u;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint32_t i = t0 + q * 256u + threadIdx.x;
+			if (i < n) {
+				const uint32_t o = atomicAdd(&at[k[q]], 1u);
+				list_out[o] = list[i];
+				range_out[o] = r[q];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// list / range (n entries, count on the device) -> list_s / range_s in the order above
+static int dust_order(pgx_reads *rd, const uint32_t *list, const uint2 *range, const uint32_t *n_ptr, size_t n_max, hipStream_t stream)
+{
+	if (n_max == 0)
+		return 0;
+	PGX_HIP(hipMemsetAsync(rd->d_dust_hist.data(), 0, 512 * sizeof(uint32_t), stream));
+	const unsigned grid = (unsigned)std::min<size_t>((n_max + 2047) / 2048, 256 * 8);
+	hipLaunchKernelGGL(k_dust_order_hist, dim3(grid), dim3(256), 0, stream, range, n_ptr, rd->d_dust_hist.data());
+	hipLaunchKernelGGL(k_dust_order_bases, dim3(1), dim3(64), 0, stream, rd->d_dust_hist.data());
+	hipLaunchKernelGGL(k_dust_order_scatter, dim3(grid), dim3(256), 0, stream, list, range, n_ptr, rd->d_dust_hist.data(), rd->d_dust_list_s.data(),
+			   rd->d_dust_range_s.data());
+	PGX_HIP(hipGetLastError());
+	return 0;
+}
+
 // the DUST window bits of a batch (reads_finish); the batch keeps them whether or not a search uses them (`-dust no`)
 int reads_dust(pgx_reads *rd)
 {
@@ -406,6 +492,9 @@ int reads_dust(pgx_reads *rd)
 	PGX_HIP(hipMemsetAsync(d_any.data(), 0, n, 0));
 	PGX_TRY(d_list.ensure(n));
 	PGX_TRY(d_range.ensure(n));
+	PGX_TRY(rd->d_dust_list_s.ensure(n));
+	PGX_TRY(rd->d_dust_range_s.ensure(n));
+	PGX_TRY(rd->d_dust_hist.ensure(512));
 	PGX_TRY(d_nlist.ensure(2));
 	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, 2 * sizeof(uint32_t), 0));
 	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
@@ -417,15 +506,17 @@ int reads_dust(pgx_reads *rd)
 	PGX_TRY(d_nlist.download(n_listed, 1));
 	if (n_listed[0]) {
 		PGX_TRY(d_list2.ensure(n_listed[0]));
+		PGX_TRY(dust_order(rd, d_list.data(), d_range.data(), d_nlist.data(), n_listed[0], 0));
 		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((n_listed[0] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, d_list.data(), d_nlist.data(), d_list2.data(), d_range.data(),
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list_s.data(), d_nlist.data(), d_list2.data(), d_range.data(),
 				   d_nlist.data() + 1);
 		PGX_HIP(hipGetLastError());
 		PGX_TRY(d_nlist.download(n_listed, 2));
 	}
 	if (n_listed[1]) {
+		PGX_TRY(dust_order(rd, d_list2.data(), d_range.data(), d_nlist.data() + 1, n_listed[1], 0));
 		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed[1] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), d_list2.data(), d_range.data(), d_nlist.data() + 1, d_mask.data(), d_any.data());
+				   rd->d_woff.data(), rd->d_dust_list_s.data(), rd->d_dust_range_s.data(), d_nlist.data() + 1, d_mask.data(), d_any.data());
 		PGX_HIP(hipGetLastError());
 	}
 	std::vector<uint8_t> &h_any = rd->h_read_dust;
@@ -468,14 +559,18 @@ int reads_dust_again(pgx_reads *rd, hipStream_t stream)
 	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
 			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, rd->d_dust_list.data(),
 			   rd->d_dust_range.data(), rd->d_dust_n.data());
-	if (rd->dust_listed[0])
+	if (rd->dust_listed[0]) {
+		PGX_TRY(dust_order(rd, rd->d_dust_list.data(), rd->d_dust_range.data(), rd->d_dust_n.data(), rd->dust_listed[0], stream));
 		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((rd->dust_listed[0] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list.data(), rd->d_dust_n.data(), rd->d_dust_list2.data(),
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list_s.data(), rd->d_dust_n.data(), rd->d_dust_list2.data(),
 				   rd->d_dust_range.data(), rd->d_dust_n.data() + 1);
-	if (rd->dust_listed[1])
+	}
+	if (rd->dust_listed[1]) {
+		PGX_TRY(dust_order(rd, rd->d_dust_list2.data(), rd->d_dust_range.data(), rd->d_dust_n.data() + 1, rd->dust_listed[1], stream));
 		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((rd->dust_listed[1] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), rd->d_dust_list2.data(), rd->d_dust_range.data(), rd->d_dust_n.data() + 1, rd->d_dust_mask.data(),
+				   rd->d_woff.data(), rd->d_dust_list_s.data(), rd->d_dust_range_s.data(), rd->d_dust_n.data() + 1, rd->d_dust_mask.data(),
 				   rd->d_dust_any.data());
+	}
 	if (rd->has_dust) {
 		PGX_HIP(hipMemsetAsync(rd->d_dustwin_f.data(), 0, n_mask * sizeof(uint64_t), stream));
 		PGX_HIP(hipMemsetAsync(rd->d_dustwin_r.data(), 0, n_mask * sizeof(uint64_t), stream));

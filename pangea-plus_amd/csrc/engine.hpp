@@ -105,6 +105,8 @@ struct pgx_reads {
 	pgx::DevBuf<uint64_t> d_dust_mask;
 	pgx::DevBuf<uint32_t> d_dust_list, d_dust_list2, d_dust_n;
 	pgx::DevBuf<uint2> d_dust_range;
+	pgx::DevBuf<uint32_t> d_dust_list_s, d_dust_hist; // a list ordered by the length of its entries' ranges; the 256 + 256 counters of that sort
+	pgx::DevBuf<uint2> d_dust_range_s;
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
 	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the
 	// stretches between such runs (seqdb.hip: reads_build_pieces): `pieces` is a batch of its own, pieces of a read
