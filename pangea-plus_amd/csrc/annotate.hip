@@ -518,17 +518,24 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 	PGX_TRY(db->d_tok_rank.alloc(db->h_tok_rank.size()));
 	PGX_TRY(db->d_tok_rank.upload(db->h_tok_rank.data(), db->h_tok_rank.size()));
 	{
-		std::vector<uint32_t> pairs(n * 16, 0);
+		// two passes: the widest record decides the stride (8 words = 32 bytes for up to 7 pairs, else 16)
 		db->max_pairs = 0;
 		for (size_t i = 0; i < n; i++) {
+			const uint32_t nt = off[i + 1] - off[i], np = (nt + 1) / 2;
+			if (!(np > 15 || nt > 0xFFFF))
+				db->max_pairs = std::max(db->max_pairs, (int)np);
+		}
+		const size_t W = db->max_pairs <= 7 ? 8 : 16;
+		db->pair_words = (int)W;
+		std::vector<uint32_t> pairs(n * W, 0);
+		for (size_t i = 0; i < n; i++) {
 			const uint32_t t0 = off[i], nt = off[i + 1] - t0, np = (nt + 1) / 2;
-			uint32_t *rec = &pairs[i * 16];
+			uint32_t *rec = &pairs[i * W];
 			if (np > 15 || nt > 0xFFFF) {
 				rec[0] = (nt & 0xFFFF) | (0xFFFFu << 16);
 				continue;
 			}
 			rec[0] = nt | (np << 16);
-			db->max_pairs = std::max(db->max_pairs, (int)np);
 			for (uint32_t a = 0; a < np; a++) {
 				const uint32_t rk = (uint32_t)(db->h_tok_rank[toks[t0 + 2 * a]] + 1);
 				const uint32_t nm = 2 * a + 1 < nt ? toks[t0 + 2 * a + 1] : 0u;
@@ -902,7 +909,7 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 static_assert(sizeof(pgx_vote_rec) == 40, "pgx_vote_rec layout");
 
 __global__ void k_vote3(const pgx_hit *__restrict__ hits, const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt,
-			const int32_t *__restrict__ soap_subj, const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ tok_off,
+			const int32_t *__restrict__ soap_subj, const uint32_t *__restrict__ pairs, uint32_t pair_words, const uint32_t *__restrict__ tok_off,
 			const uint32_t *__restrict__ tok, const int8_t *__restrict__ tok_rank, const uint32_t *__restrict__ rdp_off,
 			const uint32_t *__restrict__ rdp_code, const uint8_t *__restrict__ rdp_present, uint32_t n,
 			pgx_vote_rec *__restrict__ out)
@@ -918,7 +925,7 @@ __global__ void k_vote3(const pgx_hit *__restrict__ hits, const uint32_t *__rest
 		if (subject < 0)
 			return;
 		uint32_t seen = 0u;
-		const uint32_t *rec = pairs + 16ull * (uint32_t)subject;
+		const uint32_t *rec = pairs + (unsigned long long)pair_words * (uint32_t)subject;
 		const uint32_t np = rec[0] >> 16;
 		if (np != 0xFFFFu) {
 			for (uint32_t a = 0; a < np; a++) {
@@ -1036,7 +1043,7 @@ extern "C" int pgx_vote3_batch(const pgx_db *db, const pgx_reads *reads, const p
 		PGX_TRY(d_out.alloc(n ? n : 1));
 		if (n) {
 			hipLaunchKernelGGL(k_vote3, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, hits->d_hits.data(), hits->d_read_off.data(),
-					   hits->d_read_cnt.data(), d_subj.data(), db->d_subj_pairs.data(), db->d_subj_tok_off.data(),
+					   hits->d_read_cnt.data(), d_subj.data(), db->d_subj_pairs.data(), (uint32_t)db->pair_words, db->d_subj_tok_off.data(),
 					   db->d_subj_tok.data(), db->d_tok_rank.data(), rdp->d_off.data(), rdp->d_code.data(), rdp->d_present.data(),
 					   (uint32_t)n, d_out.data());
 			PGX_HIP(hipGetLastError());

@@ -1234,7 +1234,8 @@ struct ConsView {
 	const uint32_t *rdp_off, *rdp_name;
 	const int8_t *rdp_rank;
 	const uint8_t *rdp_present;
-	const uint32_t *subj_pairs; // 16 words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
+	const uint32_t *subj_pairs; // pair_words (8 or 16) words per subject: ntok | npairs << 16, then name << 3 | rank + 1 per pair
+	int pair_words;
 	const uint32_t *rdp_code;   // name << 3 | rank + 1 per RDP triplet
 	int dbg;                    // profiling aid (PGX_SORT_STOP): truncate k_sort_consensus after a stage
 	int np_max, nr_max;         // most pairs of any subject record / triplets of any read: the compare grid is np_max x nr_max
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ uint32_t pair_grid(const uint32_t (&pr)[15], const ui
 __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t subject, const uint32_t (&rc)[kRdpRegs],
 						  uint32_t r0, uint32_t r1, uint32_t *ntok_out)
 {
-	const uint4 *rec = reinterpret_cast<const uint4 *>(cv.subj_pairs + 16ull * subject);
+	const uint4 *rec = reinterpret_cast<const uint4 *>(cv.subj_pairs + (unsigned long long)cv.pair_words * subject);
 	const uint4 q0 = rec[0];
 	const uint32_t nt = q0.x & 0xFFFFu, np = q0.x >> 16;
 	*ntok_out = nt;
@@ -1280,7 +1281,12 @@ __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t su
 		*ntok_out = n2;
 		return rank_matches(cv.subj_tok + t0, n2, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
 	}
-	const uint4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
+	const uint4 q1 = rec[1];
+	uint4 q2 = make_uint4(0u, 0u, 0u, 0u), q3 = q2;
+	if (cv.pair_words > 8) { // (kernel-uniform: records of 32 bytes hold up to 7 pairs)
+		q2 = rec[2];
+		q3 = rec[3];
+	}
 	const uint32_t pr[15] = { q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
 	// the compare grid: 7 pairs x 6 triplets for the usual seven-rank lineages (one kernel-uniform branch), 15 x 8 otherwise
 	if (cv.np_max <= 7 && cv.nr_max <= 6)
@@ -1772,6 +1778,7 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 		cv.subj_tok = db->d_subj_tok.data();
 		cv.tok_rank = db->d_tok_rank.data();
 		cv.subj_pairs = db->d_subj_pairs.data();
+		cv.pair_words = db->pair_words;
 		cv.simrank_lut = db->d_simrank_lut.data();
 		cv.simrank_len = db->d_simrank_len.data();
 		cv.simrank_undef = db->simrank_undef;

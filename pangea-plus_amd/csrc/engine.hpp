@@ -54,6 +54,8 @@ struct pgx_db {
 	// CSR), [1..15] = (name id << 3 | rank index + 1) of each (rank,name) pair
 	pgx::DevBuf<uint32_t> d_subj_pairs;
 	int max_pairs = 15; // most pairs any subject record carries
+	int pair_words = 16; // words per subject record: 8 (32 bytes) when no subject carries more than 7 pairs -- the usual seven-rank
+			     // lineages --, else 16: the ordering kernel fetches one record per hit, and a record is a random line
 	std::vector<int8_t> h_tok_rank;
 	std::vector<int32_t> subj_taxid;
 	// distinct lineage texts (the OTUs megaclust counts): id per subject, text per id; the last id is the empty text
