@@ -122,15 +122,13 @@ def inclusive(pg, _capi, cfg, db, tmp, first, n):
     t.append(time.perf_counter())
     hits, recs = _capi.classify_consensus(db, r, p)
     t.append(time.perf_counter())
-    text = _capi.consensus_format(db, r, hits, recs)
-    with open(out, "wb") as f:
-        f.write(text)
+    n_text = _capi.consensus_format_file(db, r, hits, recs, out)   # rendered on the device, written piece by piece
     t.append(time.perf_counter())
     size = os.path.getsize(fa) + os.path.getsize(rf)
     for x in (fa, rf, out):
         os.remove(x)
     return {"value": n / (t[-1] - t[0]), "unit": "reads/s",
-            "sample": "%d reads: %.0f MB of FASTA + RDP text in, %.0f MB of consensus text out" % (n, size / 1e6, len(text) / 1e6),
+            "sample": "%d reads: %.0f MB of FASTA + RDP text in, %.0f MB of consensus text out" % (n, size / 1e6, n_text / 1e6),
             "stages_s": {"fasta_to_hbm": t[1] - t[0], "rdp_to_hbm": t[2] - t[1], "classify_consensus": t[3] - t[2],
                          "consensus_text_to_file": t[4] - t[3]}}
 

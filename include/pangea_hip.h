@@ -295,6 +295,10 @@ int pgx_vote3_format(const pgx_db *db, const pgx_reads *reads, const pgx_vote_re
 /* consensus text ("<hit line with lineage>\n#Matches found: N\n" per read), malloc'd */
 int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
 			 const pgx_consensus_rec *recs, int64_t n, char **text, size_t *len);
+/* the same text written to `path` -- the `-o` file of Consensus_BLAST_SOAP_RDP-1.1.pl:52 -- piece by piece while the next
+ * piece is rendered (no copy of the whole text on the host); *bytes = its size */
+int pgx_consensus_format_file(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits,
+			      const pgx_consensus_rec *recs, int64_t n, const char *path, size_t *bytes);
 
 /* ---- after the consensus ------------------------------------------------------
  * Megaclust/megaclust2.pl:33-163 `-i consensus.txt -o table.csv [-s PCT] [-e EVALUE] [-b BITS] [-d DELIM] [-c X] [-h]`

@@ -95,7 +95,7 @@ SYMBOLS = [
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
     "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
-    "pgx_consensus_format", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_blast_score_columns_v", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
+    "pgx_consensus_format", "pgx_consensus_format_file", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_blast_score_columns_v", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
 ]
 
 
@@ -135,6 +135,7 @@ def _declare(L):
     sig("pgx_vote3_batch", C.c_int, [V, V, V, V, C.c_char_p, V, I64])
     sig("pgx_vote3_format", C.c_int, [V, V, V, I64, V, V])
     sig("pgx_consensus_format", C.c_int, [V, V, V, V, I64, V, V])
+    sig("pgx_consensus_format_file", C.c_int, [V, V, V, V, I64, S, V])
     sig("pgx_tax_lineage_batch", C.c_int, [V, V, I64, V, V, V])
     sig("pgx_megaclust_file", C.c_int, [V, V])
     sig("pgx_megaclust_batch", C.c_int, [V, V, V, V, I64, V, V, V, V])
@@ -460,6 +461,14 @@ def consensus_format(db, reads, hits, recs):
     _check(lib().pgx_consensus_format(db.ptr, reads.ptr, hits.ptr, recs.ctypes.data, len(recs), C.byref(txt),
                                       C.byref(ln)))
     return _take_text(txt.value, ln.value)
+
+
+def consensus_format_file(db, reads, hits, recs, path):
+    """the Consensus text of a batch straight into `path` (rendered and written piece by piece); returns its size"""
+    ln = C.c_size_t()
+    recs = np.ascontiguousarray(recs, dtype=REC_DTYPE)
+    _check(lib().pgx_consensus_format_file(db.ptr, reads.ptr, hits.ptr, recs.ctypes.data, len(recs), str(path).encode(), C.byref(ln)))
+    return ln.value
 
 
 class _MegaclustOpts(C.Structure):

@@ -23,6 +23,8 @@
 
 namespace pgx {
 
+bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
+			     uint64_t piece, const std::function<int(const char *, size_t)> &sink, int *rc_out);
 bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
 			     std::string &out, int *rc_out);
 void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, Text &out);
@@ -769,28 +771,46 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		std::vector<Slot> slot;
 		size_t used = 0;
 		explicit Memo(size_t slots) : slot(slots) {}
-		// the slot of the text: *hit says whether it already holds a value
+		// the slot of the text: *hit says whether it already holds a value.  The table starts small (an RDP file names a few
+		// thousand distinct taxa: 96 KB stay in the core's cache -- the fixed 6 MB table of round 2 missed on every field, 0.28 s
+		// of the 0.56 s a 2 M-line file took) and grows fourfold when half full, up to 2^20 slots
 		Slot *find(const char *p, size_t len, bool *hit)
 		{
 			const uint64_t h = fnv64_bytes(p, len) | 1ull; // 0 marks an empty slot
-			size_t k = (size_t)(h >> 8) & (slot.size() - 1);
 			for (;;) {
-				Slot &e = slot[k];
-				if (e.h == h && e.len == len && memcmp(e.p, p, len) == 0) {
-					*hit = true;
-					return &e;
+				size_t k = (size_t)(h >> 8) & (slot.size() - 1);
+				for (;;) {
+					Slot &e = slot[k];
+					if (e.h == h && e.len == len && memcmp(e.p, p, len) == 0) {
+						*hit = true;
+						return &e;
+					}
+					if (e.h == 0)
+						break;
+					k = (k + 1) & (slot.size() - 1);
 				}
-				if (e.h == 0) {
-					*hit = false;
-					if (2 * (used + 1) > slot.size())
+				*hit = false;
+				if (2 * (used + 1) > slot.size()) {
+					if (slot.size() >= (1u << 20))
 						return nullptr;
-					e.h = h;
-					e.p = p; // (the file's text outlives the memo)
-					e.len = (uint32_t)len;
-					used++;
-					return &e;
+					std::vector<Slot> old(slot.size() * 4);
+					old.swap(slot);
+					for (const Slot &o : old) {
+						if (!o.h)
+							continue;
+						size_t j = (size_t)(o.h >> 8) & (slot.size() - 1);
+						while (slot[j].h)
+							j = (j + 1) & (slot.size() - 1);
+						slot[j] = o;
+					}
+					continue; // (probe the grown table)
 				}
-				k = (k + 1) & (slot.size() - 1);
+				Slot &e = slot[k];
+				e.h = h;
+				e.p = p; // (the file's text outlives the memo)
+				e.len = (uint32_t)len;
+				used++;
+				return &e;
 			}
 		}
 	};
@@ -804,7 +824,7 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		std::vector<std::string> &loc = t_local[t];
 		// (names: a database with 33 000 genera filled a 65 536-slot table half way, after which every field took the
 		// interning lock: 0.9 s instead of 0.5 s for 2 M lines)
-		Memo names(1 << 18), ranks(1 << 10);
+		Memo names(1 << 12), ranks(1 << 8);
 		std::vector<uint32_t> &nm = t_name[t];
 		std::vector<int8_t> &rk = t_rank[t];
 		for (size_t i = i0; i < i1; i++) {
@@ -1237,6 +1257,52 @@ int pgx_consensus_format(const pgx_db *db, const pgx_reads *reads, const pgx_hit
 	}
 	*text = out.release_malloc(len);
 	return *text ? 0 : fail(PGX_E_NOMEM, "out of memory");
+}
+
+// The same text straight into a file (`-o` of the Consensus script, Consensus_BLAST_SOAP_RDP-1.1.pl:52): rendered on the
+// device in pieces of 256 k reads; a piece is written while the next one is rendered and copied into the other of two
+// pinned buffers.  (Through pgx_consensus_format the 319 MB of a 2 M-read batch went through four host copies: 0.28 s.)
+int pgx_consensus_format_file(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs,
+			      int64_t n, const char *path, size_t *bytes_out)
+{
+	if (!db || !reads || !hits || !recs || !path)
+		return fail(PGX_E_ARG, "pgx_consensus_format_file: null argument");
+	if (!db->bound)
+		return fail(PGX_E_ARG, "pgx_consensus_format_file: database is not bound to a taxonomy");
+	if (n > reads->n)
+		n = reads->n;
+	FILE *f = fopen(path, "wb");
+	if (!f)
+		return fail(PGX_E_IO, "Unable to open %s", path);
+	size_t total = 0;
+	int drc = 0;
+	bool io_ok = true;
+	const bool on_device = consensus_format_pieces(db, reads, hits, recs, n, 256u << 10, [&](const char *p, size_t b) {
+		if (fwrite(p, 1, b, f) != b)
+			io_ok = false;
+		total += b;
+		return 0;
+	}, &drc);
+	int rc = drc;
+	if (!on_device) { // (batches of long, all-different queries: the host rendering)
+		char *text = nullptr;
+		size_t len = 0;
+		rc = pgx_consensus_format(db, reads, hits, recs, n, &text, &len);
+		if (rc == 0) {
+			io_ok = fwrite(text, 1, len, f) == len;
+			total = len;
+		}
+		free(text);
+	}
+	if (fclose(f) != 0)
+		io_ok = false;
+	if (rc < 0)
+		return rc;
+	if (!io_ok)
+		return fail(PGX_E_IO, "write to %s failed", path);
+	if (bytes_out)
+		*bytes_out = total;
+	return 0;
 }
 
 int pgx_consensus_batch(const pgx_db *db, const pgx_hits *hits, const pgx_rdp *rdp, pgx_consensus_rec *out, int64_t cap)

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <functional>
 
+#include <functional>
+#include <future>
 #include "engine.hpp"
 
 namespace pgx {
@@ -546,9 +548,11 @@ static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t 
 	return true;
 }
 
-// false: not rendered (score table too large), the caller uses its host loop
-bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
-			     std::string &out, int *rc_out)
+// The Consensus text of a batch, rendered by kernels in pieces of `piece` reads; every piece is handed to `sink` as host
+// memory (a pinned buffer, valid until the sink returns).  false: not rendered (score table too large), the caller uses its
+// host loop.
+bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
+			     uint64_t piece, const std::function<int(const char *, size_t)> &sink, int *rc_out)
 {
 	*rc_out = 0;
 	std::vector<uint32_t> len_slot, slot_base, score_off;
@@ -608,7 +612,31 @@ bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx
 		c.f.score_blob = d_score_blob.data();
 		c.recs = d_recs.data();
 		c.subj_lin = db->d_subj_lin.data();
-		const uint64_t N = (uint64_t)n, chunk = 4ull << 20;
+		const uint64_t N = (uint64_t)n, chunk = piece;
+		// two pinned buffers: the sink (a file writer) works on one piece while the next is rendered and copied
+		struct Pinned {
+			char *p = nullptr;
+			size_t cap = 0;
+			~Pinned()
+			{
+				if (p)
+					(void)hipHostFree(p);
+			}
+			int ensure(size_t n)
+			{
+				if (n <= cap)
+					return 0;
+				if (p)
+					(void)hipHostFree(p);
+				p = nullptr;
+				cap = 0;
+				PGX_HIP(hipHostMalloc((void **)&p, n + n / 8, hipHostMallocDefault));
+				cap = n + n / 8;
+				return 0;
+			}
+		} pin[2];
+		std::future<int> pending; // the sink's call on the previous piece
+		uint64_t k_piece = 0;
 		DevBuf<unsigned long long> d_len, d_off;
 		PGX_TRY(d_len.alloc(std::min(N, chunk) + 1));
 		PGX_TRY(d_off.alloc(std::min(N, chunk) + 1));
@@ -632,14 +660,32 @@ bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx
 				PGX_TRY(d_out.alloc(bytes + bytes / 8));
 			hipLaunchKernelGGL(k_fmt_consensus<true>, dim3(grid), dim3(256), 0, 0, c, r0, r1, d_off.data(), d_out.data());
 			PGX_HIP(hipGetLastError());
-			const size_t at = out.size();
-			out.resize(at + bytes);
-			PGX_HIP(hipMemcpy(&out[at], d_out.data(), bytes, hipMemcpyDeviceToHost));
+			Pinned &pb = pin[k_piece & 1];
+			PGX_TRY(pb.ensure((size_t)bytes));
+			PGX_HIP(hipMemcpy(pb.p, d_out.data(), bytes, hipMemcpyDeviceToHost));
+			if (pending.valid())
+				PGX_TRY(pending.get()); // (the piece before: its buffer is the one the NEXT piece will be copied into)
+			const char *hp = pb.p;
+			const size_t hb = (size_t)bytes;
+			pending = std::async(std::launch::async, [&sink, hp, hb]() { return sink(hp, hb); });
+			k_piece++;
 		}
+		if (pending.valid())
+			PGX_TRY(pending.get());
 		return 0;
 	};
 	*rc_out = run();
 	return true;
+}
+
+// the whole text in memory
+bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
+			     std::string &out, int *rc_out)
+{
+	return consensus_format_pieces(db, reads, hits, recs, n, 4ull << 20, [&](const char *p, size_t b) {
+		out.append(p, b);
+		return 0;
+	}, rc_out);
 }
 
 int format_hits_text(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, Text &out)

@@ -52,6 +52,11 @@ def test_fused_pipeline_equals_oracle_chain(pg, chain):
     hits, recs = _capi.classify_consensus(db, reads, rdp)
     assert hits.format(db, reads) == (chain / "hits.tsv").read_bytes()
     text = _capi.consensus_format(db, reads, hits, recs)
+    # the same text straight into a file (pgx_consensus_format_file: rendered and written piece by piece)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        assert _capi.consensus_format_file(db, reads, hits, recs, td + "/c.txt") == len(text)
+        assert open(td + "/c.txt", "rb").read() == text
     want = (chain / "consensus.txt").read_bytes()
     assert len(want) > 100000
     assert text == want
