@@ -106,6 +106,16 @@ def build_cases():
     add("jf_without_b", ["-a", "a.txt", "-j"], fa(one))
     add("jf_many", ["-a", "a.txt", "-b", "b.txt", "-j", "-g", "100"], fa([rec("k%d/1" % i, rng.randint(30, 300)) for i in range(150)]),
         fa([rec("k%d/2" % i, rng.randint(30, 300)) for i in range(150)]))
+    # quality lines of more than 60 values: positions are a + 60 x line number, so a later line can move $end BEFORE $first;
+    # $length = $end + 1 - $start is then negative, below the bareword cut-off (0), and the record is not printed at all
+    # (trim2.4.pl:404-408) -- nor is a following record whose qualities never move the range
+    def wide(name, n, q):
+        seq = bases(rng, n)
+        return (">" + name + "\n" + "\n".join(seq[i:i + 100] for i in range(0, n, 100)) + "\n",
+                ">" + name + "\n" + "\n".join(" ".join(str(v) for v in q[i:i + 100]) for i in range(0, n, 100)) + "\n")
+    q_rej = [30] * 89 + [-99999, 0] + [0] * 9 + [0] * 5 + [999999] + [1] * 20
+    pf("pf_wide_quality_lines_reject_a_record", [record(rng, "before x", 80), wide("wide1 x", len(q_rej), q_rej), wide("still x", 120, [0] * 120),
+                                                   record(rng, "after x", 90), wide("wide2 x", len(q_rej), q_rej), record(rng, "end x", 70)])
     return cases
 
 

@@ -281,7 +281,11 @@ static void parse_fasta(reader *r1, reader *rq, obuf *out)
 			break;
 		span lq = next_line(rq);
 		if (has_gt(ls)) {
-			/* length < "LENGTH_CUTOFF" (= 0) never holds: $Rejected only leaves -1 through the assignment below */
+			/* $length = $end + 1 - $start < "LENGTH_CUTOFF" (= 0): only a NEGATIVE length rejects -- quality lines of more
+			 * than 60 values can put $end before $first (positions are a + 60 x line number) -- and the record is then not
+			 * printed at all (:404-408) */
+			if (end + 1 - start < 0)
+				rejected = 1;
 			if (rejected == 0) {
 				if (header.p)
 					obuf_put(out, header.p, header.n);

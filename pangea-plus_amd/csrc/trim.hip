@@ -643,7 +643,9 @@ __global__ void k_pf_carry(FaRec *__restrict__ rec, uint64_t n_rec, uint64_t *__
 		rec[r].start = start;
 		rec[r].end = end;
 		uint64_t len = 0;
-		if (r + 1 < n_rec) {
+		// (end + 1 - start < 0 -- quality lines of more than 60 values can put the end before the start -- is the one case
+		// in which the script's $Rejected branch fires, trim2.4.pl:404-408: the record prints nothing, not even its header)
+		if (r + 1 < n_rec && end + 1 - start >= 0) {
 			const long long last = end < (long long)rec[r].n_trim - 1 ? end : (long long)rec[r].n_trim - 1;
 			const uint64_t letters = last >= start ? (uint64_t)(last - start + 1) : 0;
 			len = rec[r].hdr_len + 1 + letters + (uint64_t)((end - start + 1) / 60) + 1;
@@ -659,6 +661,8 @@ __global__ void k_pf_emit(TextView t, const uint64_t *__restrict__ hdr, uint64_t
 	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r + 1 >= n_rec)
 		return;
+	if (out_off[r + 1] == out_off[r])
+		return; // (a rejected record: nothing is printed)
 	const uint64_t h = hdr[r], stop = hdr[r + 1];
 	const FaRec o = rec[r];
 	char *w = out + out_off[r];
