@@ -134,10 +134,12 @@ __device__ __forceinline__ uint32_t scan_low(uint32_t y)
 // window holds: the unsigned minimum drops them, and turns "no mismatch" (-1 from the bit scan) into the cap.
 // Only ascending: the side LEFT of the anchor is staged reversed (see k_gapped_fast), so one copy of the row code serves
 // both sides -- half the instruction footprint of the kernel.
+// (the list tiers' letters lie in TRANSPOSED rows too since round 3: word i of a lane at w[i * 64], its own LDS bank)
+constexpr int kLaneWordStride = 64;
 __device__ __forceinline__ uint32_t lds_window16_bits(const uint32_t *w, int bit)
 {
 	const int i = bit >> 5;
-	return __builtin_amdgcn_alignbit(w[i + 1], w[i], (uint32_t)bit);
+	return __builtin_amdgcn_alignbit(w[(i + 1) * kLaneWordStride], w[i * kLaneWordStride], (uint32_t)bit);
 }
 
 __device__ __forceinline__ int lcp16(const uint32_t *rd, const uint32_t *db, int qbit, int dbit, int cap)
@@ -794,9 +796,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 	uint32_t *order = order_all + (size_t)blockIdx.x * kBlkItems; // written and read by this wavefront only, through L2
 	const int lane = threadIdx.x & 63;
 	// word w of the lane's staged read letters / database window
-	uint32_t *rdw = LEAN ? &lds.seq[kLeanFrontRows * 64 + lane] : &lds.seq[lane * Lds::kSeq];
-	uint32_t *dbwin = LEAN ? rdw + Lds::kRd * 64 : rdw + Lds::kRd;
-	constexpr int WS = LEAN ? 64 : 1; // stride of a lane's words
+	uint32_t *rdw = LEAN ? &lds.seq[kLeanFrontRows * 64 + lane] : &lds.seq[lane];
+	uint32_t *dbwin = rdw + Lds::kRd * 64;
+	constexpr int WS = kLaneWordStride; // stride of a lane's words (row r of lane l at seq[r * 64 + l])
 	const unsigned long long n_flat_raw = FLAT ? (LIST ? (unsigned long long)*reinterpret_cast<const uint32_t *>(flat_count) : *flat_count) : 0ull;
 	const unsigned long long n_flat = n_flat_raw < table_cap ? n_flat_raw : table_cap;
 	// (with 2 048 entries per block the few listed HSPs of a short-read batch all fell to one or two wavefronts)
