@@ -714,7 +714,8 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		const size_t e = i + 1 < n_lines ? ls[i + 1] - 1 : (text.size() && text.back() == '\n' ? text.size() - 1 : text.size());
 		*len = e - ls[i];
 	};
-	const unsigned hw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_lines / 4096 + 1));
+	const unsigned hw_env = getenv("PGX_RDP_THREADS") ? (unsigned)atoi(getenv("PGX_RDP_THREADS")) : 0u; // (measurement aid)
+	const unsigned hw = hw_env ? hw_env : (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_lines / 4096 + 1));
 	auto parallel = [&](const std::function<void(unsigned, size_t, size_t)> &f) {
 		std::vector<std::thread> th;
 		for (unsigned t = 0; t < hw; t++)
@@ -774,9 +775,10 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		// the slot of the text: *hit says whether it already holds a value.  The table starts small (an RDP file names a few
 		// thousand distinct taxa: 96 KB stay in the core's cache -- the fixed 6 MB table of round 2 missed on every field, 0.28 s
 		// of the 0.56 s a 2 M-line file took) and grows fourfold when half full, up to 2^20 slots
-		Slot *find(const char *p, size_t len, bool *hit)
+		Slot *find(const char *p, size_t len, bool *hit) { return find_h(p, len, fnv64_bytes(p, len), hit); }
+		Slot *find_h(const char *p, size_t len, uint64_t hash, bool *hit) // hash = fnv64_bytes(p, len)
 		{
-			const uint64_t h = fnv64_bytes(p, len) | 1ull; // 0 marks an empty slot
+			const uint64_t h = hash | 1ull; // 0 marks an empty slot
 			for (;;) {
 				size_t k = (size_t)(h >> 8) & (slot.size() - 1);
 				for (;;) {
@@ -827,6 +829,11 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		Memo names(1 << 12), ranks(1 << 8);
 		std::vector<uint32_t> &nm = t_name[t];
 		std::vector<int8_t> &rk = t_rank[t];
+		// (room for the usual seven triplets a line up front: growing the vectors by doubling made this pass SLOWER with
+		// more threads -- 0.27 s on one, 0.60 s on four -- every regrowth maps and unmaps tens of megabytes under the
+		// process's one address-space lock)
+		nm.reserve((i1 - i0) * 8 + 64);
+		rk.reserve((i1 - i0) * 8 + 64);
 		for (size_t i = i0; i < i1; i++) {
 			const size_t r = line_read[i];
 			if (r >= n || !has_five[i])
@@ -836,23 +843,29 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			line_of(i, &line, &len);
 			const char *rest = line + id_len[i] + 5;
 			size_t rest_len = len - id_len[i] - 5;
+			// (a second five-tab group ends the fields, as before; then ONE walk over the bytes: a field ends at a tab and its
+			// FNV hash is made on the way -- a memchr and a separate hash pass per field were most of this pass)
 			if (const char *again = (const char *)memmem(rest, rest_len, kFive, 5))
 				rest_len = (size_t)(again - rest);
 			while (rest_len && rest[rest_len - 1] == '\t') // trailing empty fields are dropped
 				rest_len--;
-			// fields in threes: name, rank, confidence
-			size_t a = 0;
-			for (int k = 0; a <= rest_len && (rest_len || k == 0); k++) {
-				const char *tb = (const char *)memchr(rest + a, '\t', rest_len - a);
-				const size_t fe = tb ? (size_t)(tb - rest) : rest_len;
+			if (rest_len == 0)
+				continue;
+			size_t a = 0; // start of the current field
+			uint64_t fh = 1469598103934665603ull;
+			int k = 0;
+			for (size_t x = 0; x <= rest_len; x++) {
+				if (x < rest_len && rest[x] != '\t') {
+					fh = (fh ^ (unsigned char)rest[x]) * 1099511628211ull;
+					continue;
+				}
+				// field k = rest[a, x)
 				if (k % 3 == 0) {
-					if (rest_len == 0)
-						break;
 					bool hit;
-					Memo::Slot *e = names.find(rest + a, fe - a, &hit);
+					Memo::Slot *e = names.find_h(rest + a, x - a, fh, &hit);
 					uint32_t tok = hit ? e->value : 0u;
 					if (!hit) {
-						const std::string clean = clean_rdp_name(std::string(rest + a, fe - a));
+						const std::string clean = clean_rdp_name(std::string(rest + a, x - a));
 						auto it = lmap.find(clean);
 						if (it == lmap.end()) {
 							it = lmap.emplace(clean, (uint32_t)loc.size()).first;
@@ -867,15 +880,15 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 					trips[r]++; // (one line per read: no two threads touch one counter)
 				} else if (k % 3 == 1) {
 					bool hit;
-					Memo::Slot *e = ranks.find(rest + a, fe - a, &hit);
-					uint32_t rv = hit ? e->value : (uint32_t)(uint8_t)rdp_rank_index(std::string(rest + a, fe - a));
+					Memo::Slot *e = ranks.find_h(rest + a, x - a, fh, &hit);
+					uint32_t rv = hit ? e->value : (uint32_t)(uint8_t)rdp_rank_index(std::string(rest + a, x - a));
 					if (!hit && e)
 						e->value = rv;
 					rk.back() = (int8_t)rv;
 				}
-				if (!tb)
-					break;
-				a = fe + 1;
+				k++;
+				a = x + 1;
+				fh = 1469598103934665603ull;
 			}
 		}
 	});
