@@ -1818,6 +1818,231 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 	}
 }
 
+// ------------------------------------------------------------------------------------------ one wavefront per HSP, one LANE per diagonal
+// Round 3.  k_gapped_big keeps a level's cells in LDS, two rows of (i, statistics), read through three
+// guarded loads per cell, and finds the level's best with six shuffles: ~850 SIMD cycles per level, the whole of config 2's
+// 14.6 ms.  Here the level IS the wavefront: lane l holds the cell of diagonal k = l - 32 in ONE register (the lean word of
+// the first tier: i << 17 | priority << 14 | statistics), its neighbours come by DPP wave shifts, no LDS row, no barrier.
+// The live diagonals of an X-drop alignment stay within 2 X / 6 + 1 = 19 of the best one, so 64 lanes hold them unless the
+// path itself drifts by > ~12 net gap columns; an HSP whose live cells reach lane 0 or 63 is passed on to k_gapped_big.
+//   statistics (14 bits): gap openings [5:0] | open-gap kind [7:6] | G1 = gap columns in the subject row [13:8].  The kind
+//   is stored AS THE PRIORITY of the column that made it (1: from k - 1, a gap in the subject row; 0: from k + 1, a gap in
+//   the query row; 2: none -- a mismatch column, or letters matched after the gap), so "this gap column continues the
+//   parent's open gap" is one XOR of two fields of the winning parent's word.  Mismatches = d - gap columns, gap columns in
+//   the query row = G1 - k.  A field that nears 62 hands the HSP on.
+//   best cell: every lane keeps the best of ITS diagonal (score << 10 | 1023 - d: first d among equal scores) and the word
+//   of that cell; one reduction at the end of the side picks the first lane among the best.  The X-drop history T[d] (best
+//   score within d differences) needs the wave's maximum per level: six DPP steps; T itself lies across the lanes of one
+//   register (lane d & 63 holds T[d]: the test of level d reads T[d - 19]).
+// Letters: the side's part of the read and the subject window, forward in the direction of extension (the left side
+// reversed, as in the lean rows), 1.1 KB of LDS per wavefront.
+constexpr int kDiagL = 2048;                       // longest read this kernel stages
+constexpr int kDiagFront = 3;                      // spare words in front of each sequence (dead cells and diagonals k > i read there)
+constexpr int kDiagQW = kDiagFront + kDiagL / 16 + 5;
+constexpr int kDiagDW = kDiagFront + (kDiagL + 64) / 16 + 6;
+constexpr uint32_t kDiagDead = 0xFFF80000u;        // i = -4
+constexpr uint32_t kDiagFromCur = 0x28000u;        // i + 1, priority 2
+constexpr uint32_t kDiagFromPrev = 0x24100u;       // i + 1, priority 1, G1 + 1
+struct DiagLds {
+	uint32_t seq[kDiagQW + kDiagDW];
+};
+
+__device__ __forceinline__ int dpp_from_lower(int v, int dead) { return __builtin_amdgcn_update_dpp(dead, v, 0x138, 0xf, 0xf, false); } // lane l <- lane l - 1
+__device__ __forceinline__ int dpp_from_upper(int v, int dead) { return __builtin_amdgcn_update_dpp(dead, v, 0x130, 0xf, 0xf, false); } // lane l <- lane l + 1
+// the wavefront's maximum, in every lane
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false)); // row_shr:1
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false)); // row_shr:2
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false)); // row_shr:4
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false)); // row_shr:8  -> lane 15 of each row holds the row's maximum
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
+	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+	return __builtin_amdgcn_readlane(v, 63);
+}
+
+// 16 letters at letter position p of packed words g (16 letters per word), words outside [w_lo, w_hi] read as zero
+__device__ __forceinline__ uint32_t diag_window(const uint32_t *g, int64_t p, int64_t w_lo, int64_t w_hi)
+{
+	const int64_t w = p >> 4;
+	const uint32_t lo = w >= w_lo && w <= w_hi ? g[w] : 0u, hi = w + 1 >= w_lo && w + 1 <= w_hi ? g[w + 1] : 0u;
+	return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(p & 15) * 2u);
+}
+
+// one side.  seq0: the staged letters (read part at word 0, subject window at word kDiagQW, letter 0 of each kDiagFront
+// words in); M, N = letters of the read / of the subject on the side.  Returns 0 done, 1 hand the HSP on.
+__device__ __forceinline__ int diag_side(const lds_word *seq0, int M, int N, Side &out)
+{
+	const int lane = threadIdx.x & 63, k = lane - 32;
+	constexpr int QB = 32 * kDiagFront, DBb = 32 * (kDiagQW + kDiagFront);
+	auto ld = [&](uint32_t bit) { // the 16 letters from bit offset `bit` of the staged words on
+		const uint32_t a = (bit >> 3) & 0xFFFFFFFCu;
+		return __builtin_amdgcn_alignbit(lds_ld(seq0, a + 4), lds_ld(seq0, a), bit);
+	};
+	auto lcp2 = [&](uint32_t qb, uint32_t db, uint32_t cap2) { // matching letters as bits: min(32, cap2, 2 run)
+		const uint32_t x = ld(qb) ^ ld(db);
+		const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+		return min3u(scan_low(y), 32u, cap2);
+	};
+	// ---- the first run (the same in every lane)
+	int i2 = 0;
+	for (;;) {
+		const int cap2 = min(2 * M, 2 * N) - i2;
+		if (cap2 <= 0)
+			break;
+		const uint32_t r2 = lcp2((uint32_t)(QB + i2), (uint32_t)(DBb + i2), (uint32_t)cap2);
+		i2 += (int)r2;
+		if (r2 < 32u)
+			break;
+	}
+	out.i = out.j = i2 >> 1;
+	out.s2 = i2;
+	out.mism = out.gopen = 0;
+	if (i2 == 2 * M || i2 == 2 * N)
+		return 0;
+	// per-lane constants of the diagonal
+	const int E = min(2 * M, 2 * N + 2 * k) + QB;   // end of the shorter sequence on this diagonal, as a read bit offset
+	const int F = min(2 * M - k, 2 * N + k);        // the bound of a cell of this diagonal, before the 6 d
+	const uint32_t Qc = (uint32_t)QB << 16, Dl = (uint32_t)(DBb - QB - 2 * k) << 16;
+	const int k16 = (int)((uint32_t)k << 16);
+	int R = lane == 32 ? (int)(((uint32_t)i2 << 16) | 0x80u) : (int)kDiagDead;
+	int lane_key = lane == 32 ? (i2 << 10) | 1023 : (int)0x80000000u;
+	int lane_word = R;
+	int best = i2;   // wave-uniform
+	int T = i2;      // lane (d & 63) holds T[d]; lane 0: T[0]
+	int status = 0;
+	for (int d = 1; d <= kGDmax; d++) {
+		const int tcmp = d >= kGLag ? __builtin_amdgcn_readlane(T, (d - kGLag) & 63) : 0;
+		const int thr16 = (int)((uint32_t)(tcmp - kGX2 + 6 * d) << 16); // 2 i - k >= tcmp - 2 X + 6 d, on the word's upper half
+		const int a = R + (int)kDiagFromCur, b = dpp_from_lower(R, (int)kDiagDead) + (int)kDiagFromPrev, c = dpp_from_upper(R, (int)kDiagDead);
+		const int m3 = max(a, max(b, c));
+		const uint32_t t = (uint32_t)m3 + Qc, u = t + Dl;
+		const uint32_t qbit = (uint32_t)((int)t >> 16), dbit = (uint32_t)((int)u >> 16);
+		const int cap2 = E - (int)qbit;
+		// (m3 - k16 compares the word's upper half with the threshold: the low half is below 2^16 and k16, thr16 have none)
+		const bool ok = ((m3 | cap2) >= 0) & (F - 6 * d > best) & ((m3 & (int)0xFFFF0000u) - k16 >= thr16);
+		uint32_t r2 = lcp2(qbit, dbit, (uint32_t)cap2);
+		// statistics of the winning parent -> of this cell
+		const uint32_t w = (uint32_t)m3;
+		const uint32_t pk = (w >> 8) & 0xC0u;                         // the priority, where the kind lies
+		const uint32_t differs = ((w ^ pk) & 0xC0u) != 0u ? 1u : 0u;  // the parent's open gap is not of this column's kind
+		const uint32_t inc = (w & 0x8000u) ? 0u : differs;            // a gap column (priority 0 or 1) that opens a gap
+		// letters past the first 16
+		int q2 = (int)(w >> 16) + (int)r2; // 2 i (m3 >= 0 where it counts)
+		bool more = ok && r2 == 32u;
+		const bool slid = r2 != 0u;
+		while (__ballot(more) != 0ull) {
+			if (more) {
+				const int c2 = E - (QB + q2);
+				if (c2 <= 0) {
+					more = false;
+				} else {
+					const uint32_t rr = lcp2((uint32_t)(QB + q2), (uint32_t)((int)(Dl >> 16) + QB + q2), (uint32_t)c2);
+					q2 += (int)rr;
+					more = rr == 32u;
+				}
+			}
+		}
+		const uint32_t nc = ((uint32_t)q2 << 16) | (((w & 0x3F3Fu) + inc) | (slid ? 0x80u : pk));
+		const int nv = ok ? (int)nc : (int)kDiagDead;
+		const int s2 = (nv >> 16) - k - 6 * d;
+		const int key = nv >= 0 ? (int)((uint32_t)s2 << 10) + (1023 - d) : (int)0x80000000u;
+		if (key > lane_key) {
+			lane_key = key;
+			lane_word = nv;
+		}
+		R = nv;
+		const unsigned long long am = __ballot(nv >= 0);
+		if (am == 0ull)
+			break;
+		// live cells at the wavefront's ends, or a statistics field about to overflow: the wide kernel takes the HSP
+		const bool near_full = nv >= 0 && ((((uint32_t)nv & 0x3F3Fu) + 0x0202u) & 0x4040u) != 0u;
+		if ((am & 0x8000000000000001ull) != 0ull || __ballot(near_full) != 0ull) {
+			status = 1;
+			break;
+		}
+		best = max(best, wave_max_i32(nv >= 0 ? s2 : (int)0x80000000u));
+		T = lane == (d & 63) ? best : T;
+	}
+	if (status)
+		return status;
+	const int top = wave_max_i32(lane_key);
+	const int wl = __ffsll((unsigned long long)__ballot(lane_key == top)) - 1;
+	const uint32_t st = (uint32_t)__builtin_amdgcn_readlane(lane_word, wl);
+	const int bk = wl - 32, bd = 1023 - (top & 1023);
+	const int g1 = (int)((st >> 8) & 63u), g2 = g1 - bk;
+	out.s2 = top >> 10;
+	out.i = (int)(st >> 17);
+	out.j = out.i - bk;
+	out.gopen = (int)(st & 63u);
+	out.mism = bd - (g1 + g2);
+	return 0;
+}
+
+__global__ __launch_bounds__(64) void k_gapped_diag(GapView v, const unsigned long long *__restrict__ list, const uint32_t *__restrict__ count, uint32_t cap,
+						     unsigned long long *__restrict__ next_list, uint32_t *__restrict__ next_count)
+{
+	__shared__ DiagLds lds;
+	const lds_word *seq0 = (const lds_word *)&lds.seq[0];
+	const int lane = threadIdx.x & 63;
+	const uint32_t n = *count < cap ? *count : cap;
+	for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+		pgx_hit *hp = reinterpret_cast<pgx_hit *>((uintptr_t)list[idx]);
+		const pgx_hit h = *hp;
+		const Anchor a = anchor_of(v, h);
+		bool fits = a.L <= kDiagL;
+		// ambiguity letters (read or window): the wide kernel reads those HSPs in memory, flag words and all
+		const int64_t g_lo = (int64_t)a.gpos - a.qa - 160, g_hi = (int64_t)a.gpos + (a.L - a.qa) + 160; // every letter either side may stage
+		if (fits) {
+			bool amb = false;
+			if (a.s.ra)
+				for (int w = lane; w < (a.L + 31) / 32; w += 64)
+					amb = amb || a.s.ra[w] != 0;
+			if (a.s.dba) {
+				if (v.amb_blk) {
+					// (letters outside the database read as zero below and lie beyond every cap)
+					const int64_t b0 = g_lo >> kBlkShift, b1 = (g_hi < v.db_bases ? g_hi : v.db_bases - 1) >> kBlkShift;
+					for (int64_t bb = (b0 < 0 ? 0 : b0) + lane; bb <= b1; bb += 64)
+						amb = amb || ((v.amb_blk[bb >> 5] >> (bb & 31)) & 1u);
+				} else {
+					amb = true;
+				}
+			}
+			fits = __ballot(amb) == 0ull;
+		}
+		Side sd[2];
+		int status = fits ? 0 : 1;
+		const uint32_t *gr = reinterpret_cast<const uint32_t *>(a.s.rw), *gd = reinterpret_cast<const uint32_t *>(a.s.dbw);
+		const int64_t rd_hi = a.L / 16 + 1, db_lo = -(int64_t)(kDbPadBases / 16), db_hi = (v.db_bases + kDbPadBases) / 16 - 1;
+		for (int side = 0; side < 2 && status == 0; side++) {
+			// side 0: left of the anchor, reversed (letter y of the staged read part = read letter qa - 1 - y); side 1: right
+			const int M = side ? a.L - a.qa : a.qa, N = side ? a.slen - a.sa : a.sa;
+			const int nq = kDiagFront + (M + 34) / 16 + 2, nd = kDiagFront + (M + 32 + 34) / 16 + 3;
+			for (int x = lane; x < nq; x += 64) {
+				const int y0 = 16 * (x - kDiagFront); // first staged letter of the word
+				lds.seq[x] = side ? diag_window(gr, (int64_t)a.qa + y0, 0, rd_hi) : __builtin_bitreverse32(diag_window(gr, (int64_t)a.qa - 1 - y0 - 15, 0, rd_hi));
+			}
+			for (int x = lane; x < nd; x += 64) {
+				const int y0 = 16 * (x - kDiagFront);
+				lds.seq[kDiagQW + x] = side ? diag_window(gd, (int64_t)a.gpos + y0, db_lo, db_hi)
+							     : __builtin_bitreverse32(diag_window(gd, (int64_t)a.gpos - 1 - y0 - 15, db_lo, db_hi));
+			}
+			lds_sync();
+			status = diag_side(seq0, M, N, sd[side]);
+			lds_sync();
+		}
+		if (lane == 0) {
+			if (status == 0) {
+				write_gapped(hp, h, a, sd[0], sd[1]);
+			} else if (next_list) {
+				const uint32_t w = atomicAdd(next_count, 1u);
+				if (w < cap)
+					next_list[w] = list[idx];
+			}
+		}
+	}
+}
+
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
 		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used, const uint8_t *main_reg)
@@ -1839,7 +2064,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const unsigned long long want = long_reads ? hit_cap + ovf_cap : std::max<unsigned long long>(1ull << 20, (hit_cap + ovf_cap) / 16);
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
-	PGX_TRY(gw.big_count.ensure(4));
+	PGX_TRY(gw.big_count.ensure(8));
 	const bool binned = !long_reads && getenv("PGX_GAP_POOLS1") == nullptr; // (PGX_GAP_POOLS1=1: the one-pass pools, for comparison)
 	const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;                // (PGX_GAP_POOLS2=1: the two-pass pools, for comparison)
 	if (binned) {
@@ -1858,7 +2083,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const uint32_t cap = (uint32_t)std::min<size_t>(gw.big_list.n, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list2.ensure(cap));
 	PGX_TRY(gw.side_list.ensure(long_reads ? 1 : cap));
-	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 4 * sizeof(uint32_t), stream));
+	PGX_HIP(hipMemsetAsync(gw.big_count.data(), 0, 8 * sizeof(uint32_t), stream));
 	const uint32_t n = rv.n;
 	const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 63) / 64, 256ull * 40);
 	const int dbg = 0; // (round 2's truncation probes are gone: a truncated stage leaves seed records where the stages behind expect hits)
@@ -1875,7 +2100,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		hipLaunchKernelGGL(k_seg_scatter, dim3(256 * 8), dim3(256), 0, stream, gw.keys1.data(), gw.items1.data(), gw.bins.data(), gw.items.data());
 	}
 	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
-	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's)
+	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's), [4] E (in A's)
 	// (long reads: every HSP goes straight to the wide kernels, which read list A)
 	const TierLists tl = { listA, long_reads ? listA : listB, cnt, long_reads ? cnt : cnt + 1, cap };
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
@@ -1924,12 +2149,19 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 				   reinterpret_cast<pgx_hit *>(listB), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
 				   reinterpret_cast<const unsigned long long *>(cnt + 1), listA, cnt + 2, cap,
 				   gw.side_list.data(), 0, gw.order.data());
-	const unsigned long long *l62 = listA;
-	unsigned long long *l1000 = listB;
-	const uint32_t *c62 = long_reads ? cnt : cnt + 2;
-	hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, l62, c62, cap, l1000, cnt + 3);
-	hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)l1000, cnt + 3, cap,
-			   (unsigned long long *)nullptr, (uint32_t *)nullptr);
+	// (list C, or list A itself for long reads) -> one lane per diagonal -> D -> the LDS rows for 62 differences -> E -> for 1 000
+	const uint32_t *c_diag = long_reads ? cnt : cnt + 2;
+	static const bool no_diag = getenv("PGX_GAP_NODIAG") != nullptr; // (measurement aid: the wide kernels alone, as in round 2)
+	if (no_diag) {
+		hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, (const unsigned long long *)listA, c_diag, cap, listB, cnt + 3);
+		hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)listB, cnt + 3, cap,
+				   (unsigned long long *)nullptr, (uint32_t *)nullptr);
+	} else {
+		hipLaunchKernelGGL(k_gapped_diag, dim3(256 * 32), dim3(64), 0, stream, v, (const unsigned long long *)listA, c_diag, cap, listB, cnt + 3);
+		hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, (const unsigned long long *)listB, cnt + 3, cap, listA, cnt + 4);
+		hipLaunchKernelGGL(k_gapped_big<kGDmax>, dim3(256 * 8), dim3(64), 0, stream, v, (const unsigned long long *)listA, cnt + 4, cap,
+				   (unsigned long long *)nullptr, (uint32_t *)nullptr);
+	}
 	PGX_HIP(hipGetLastError());
 	return 0;
 }
