@@ -663,6 +663,16 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 					kr = (2 * (L - anchor) - b0r) / 5;
 					kl = kl < 14 ? kl : 14;
 					kr = kr < 14 ? kr : 14;
+					if (L > 320) {
+						// reads the gapped stage runs with 40 differences a side (gapped.hip: greedy_rows_deep): B0 says nothing
+						// beyond 18 mismatches, and half the sides of a 500-base read at 7 % hold more.  Its rounds are ordered by
+						// the diagonal's own mismatch count, three levels to a step, plus the ~10 levels a side runs on past an
+						// extension that the drop-off ended inside the read
+						kl = (ml + (bl > 0 ? 10 : 0)) / 3;
+						kr = (mr + (br + 1 < L ? 10 : 0)) / 3;
+						kl = kl < 14 ? kl : 14;
+						kr = kr < 14 ? kr : 14;
+					}
 				}
 				h.qstart = (int32_t)woff;
 				h.qend = anchor;

@@ -720,6 +720,273 @@ __device__ __forceinline__ int greedy_rows_lean(const lds_word *seq0, uint32_t l
 	return g1 >= 2 || g2 >= 2 ? 2 : 0;
 }
 
+// The lean rows for D >= kGLag differences a side (reads of 320-512 bases: at 7 % divergence most sides of a 500-base read
+// need 19-40 levels; round 2's 40-difference tier with the per-cell statistics took 73 of the 145 ms per 1 M such reads).
+// Differences to greedy_rows_lean: the X-drop test (T[d - 19] in a 19-register ring that shifts once per level); the
+// cell's low 14 bits carry gap openings [5:0] | open-gap kind [7:6] | G1 [13:8] as in k_gapped_diag (with 19-40 levels
+// most best paths hold two gap columns of a kind, which the G1-only word cannot count), the best cell's word is kept
+// beside the running maximum of  score << 16 | 65535 - (d * 128 + k + 64).
+// status: 0 done, 1 cells alive after D differences (next tier)
+// seq0 = the letter rows (row r of lane l at byte r * 256 + l * 4), lane4 = l * 4; QB / DB0 = bit offsets of the side's first read / database
+// letter there; M, N = letters of the read / of the subject on the side; b0 as for greedy_rows
+constexpr uint32_t kDeepFromPrev = 0x24100u; // i + 1, priority 1, G1 + 1 (G1 at bit 8)
+template <int D>
+__device__ __forceinline__ int greedy_rows_deep(const lds_word *seq0, uint32_t lane4, bool on, int QB, int DB0, int M, int N, int b0, Side &out)
+{
+	static_assert(D >= kGLag && D < 62, "X-drop history kept, 6-bit fields");
+	constexpr int kCells = 2 * D + 3, C = D + 1;
+	const int A2 = 2 * M + QB, B2 = 2 * N + QB; // ends of the two sequences as read bit offsets (B2 + 2 k on diagonal k)
+	// ---- the first run
+	int i2 = 0; // 2 i
+	if (on) {
+		for (;;) {
+			const int cap2 = min(2 * M, 2 * N) - i2;
+			if (cap2 <= 0)
+				break;
+			const uint32_t r2 = lean_lcp(seq0, lane4, (uint32_t)(QB + i2), (uint32_t)(DB0 + i2), (uint32_t)cap2);
+			i2 += (int)r2;
+			if (r2 < 32u)
+				break;
+		}
+	}
+	out.i = out.j = i2 >> 1;
+	out.s2 = i2;
+	out.mism = out.gopen = 0;
+	bool live = on && !(i2 == 2 * M || i2 == 2 * N);
+	uint32_t R[kCells];
+#pragma unroll
+	for (int c = 0; c < kCells; c++)
+		R[c] = kLeanDead;
+	R[C] = live ? ((uint32_t)i2 << 16) | 0x80u : kLeanDead;
+	// order of a cell: d * 128 + k + 64 (the first run: 64); key = s2 << 16 | 65535 - order
+	int best_key = (i2 << 16) | (65535 - 64);
+	uint32_t best_word = ((uint32_t)i2 << 16) | 0x80u;
+	int Tr[kGLag]; // T[d - 19 .. d - 1] while level d runs (T[x] = best score within x differences; x < 0: no test)
+#pragma unroll
+	for (int x = 0; x < kGLag; x++)
+		Tr[x] = -(1 << 14);
+	Tr[kGLag - 1] = i2;
+	int thrk = 0; // running per cell: (T[d - 19] - 2 X + 6 d + k) << 16, the X-drop threshold on the word's upper half
+	const uint32_t Qc = (uint32_t)QB << 16;
+	const uint32_t D0 = (uint32_t)(DB0 - QB) << 16;
+	const uint32_t c17 = 0x20000u;
+	uint32_t prev = kLeanDead;
+	// per level, per lane: the diagonals k the bound lets live are lo1 .. lo1 + width (none: lo1 = 1 << 20)
+	int lo1 = 0;
+	uint32_t width = 0;
+	uint32_t alldead = 0xFFFFFFFFu; // AND of the level's new cells: negative while every one of them is dead
+	auto set_range = [&](int d) { // for level d, from the best score so far
+		const int best = max(best_key >> 16, b0 - 1);
+		const int lo = 6 * d - (2 * N - best) + 1, hi = (2 * M - best) - 6 * d - 1; // lo <= k <= hi
+		const bool some = lo <= hi;
+		lo1 = some ? lo : (1 << 20);
+		width = some ? (uint32_t)(hi - lo) : 0u;
+		return some && lo <= d && hi >= -d;
+	};
+	// running per-cell values of a level (k ascending): Dk = D0 - k << 17, Bk = B2 + 2 k, rk = k - lo1
+	uint32_t Dk = 0, rk = 0;
+	int Bk = 0;
+	auto level_start = [&](int d) {
+		Dk = D0 + ((uint32_t)d << 17);
+		Bk = B2 - 2 * d;
+		rk = (uint32_t)(-d - lo1);
+		prev = kLeanDead;
+		alldead = 0xFFFFFFFFu;
+		thrk = (int)((uint32_t)(Tr[0] - kGX2 + 6 * d - d) << 16);
+	};
+	// one cell; c compile-time; ckd = -(k + 6 d) << 16 | (2047 - order) << 5, wave-uniform
+	auto cell = [&](auto cc, auto reach_c, int ckd, uint32_t &r2_out) {
+		constexpr int c = decltype(cc)::value;
+		constexpr int k = c - C;
+		constexpr int reach = decltype(reach_c)::value;
+		const uint32_t cur = R[c], nxt = R[c + 1];
+		int m3;
+		if constexpr (k < -reach)
+			m3 = (int)nxt; // the left edge of the level: only diagonal k + 1 can lead here
+		else if constexpr (k > reach)
+			m3 = (int)(prev + kDeepFromPrev); // the right edge: only diagonal k - 1
+		else if constexpr (k - 1 < -reach && k + 1 > reach)
+			m3 = (int)(cur + kLeanFromCur); // level 1, k = 0
+		else if constexpr (k - 1 < -reach)
+			m3 = max((int)(cur + kLeanFromCur), (int)nxt);
+		else if constexpr (k + 1 > reach)
+			m3 = max((int)(cur + kLeanFromCur), (int)(prev + kDeepFromPrev));
+		else
+			m3 = max((int)(cur + kLeanFromCur), max((int)(prev + kDeepFromPrev), (int)nxt));
+		const uint32_t t = (uint32_t)m3 + Qc, u = t + Dk;
+		const uint32_t qbit = (uint32_t)((int)t >> 16), dbit = (uint32_t)((int)u >> 16);
+		const uint32_t qa = ((t >> 13) & 0xFFFFFF00u) | lane4, da = ((u >> 13) & 0xFFFFFF00u) | lane4;
+		const int cap2 = min(A2, Bk) - (int)qbit;
+		bool ok = ((m3 | cap2) >= 0) & (rk <= width);
+		if constexpr (reach >= kGLag - 1) // (levels below kGLag pass every X-drop test)
+			ok = ok & ((int)((uint32_t)m3 & 0xFFFF0000u) >= thrk);
+		const uint32_t x = __builtin_amdgcn_alignbit(lds_ld(seq0, qa + 256), lds_ld(seq0, qa), qbit) ^ __builtin_amdgcn_alignbit(lds_ld(seq0, da + 256), lds_ld(seq0, da), dbit);
+		const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+		const uint32_t r2 = min3u(scan_low(y), 32u, (uint32_t)cap2);
+		// the winning parent's statistics -> this cell's (see k_gapped_diag)
+		const uint32_t w = (uint32_t)m3;
+		const uint32_t pk = (w >> 8) & 0xC0u;
+		const uint32_t differs = ((w ^ pk) & 0xC0u) != 0u ? 1u : 0u;
+		const uint32_t inc = (w & 0x8000u) ? 0u : differs;
+		const uint32_t nc = ((w & 0xFFFF0000u) + (r2 << 16)) | (((w & 0x3F3Fu) + inc) | (r2 != 0u ? 0x80u : pk));
+		const uint32_t nv = ok ? nc : kLeanDead;
+		{
+			const int key = (int)((nv & 0xFFFF0000u) + (uint32_t)ckd);
+			best_word = key > best_key ? nv : best_word;
+			best_key = max(best_key, key);
+		}
+		alldead &= nv;
+		r2_out = r2;
+		prev = cur;
+		R[c] = nv;
+		Dk -= c17;
+		Bk += 2;
+		rk += 1u;
+		thrk += 0x10000;
+	};
+	// a cell whose first 16 letters all matched and that has more to compare: slide on (rare off the alignment's own diagonal)
+	auto slide_on = [&](auto cc, int ckd, uint32_t r2) {
+		constexpr int c = decltype(cc)::value;
+		constexpr int k = c - C;
+		const uint32_t w = R[c];
+		bool more = (int)w >= 0 && r2 == 32u;
+		if (__ballot(more) == 0ull)
+			return;
+		int q2 = (int)w >> 16; // 2 i
+		while (more) {
+			const int cap2 = min(A2, B2 + 2 * k) - (QB + q2);
+			if (cap2 <= 0)
+				break;
+			const uint32_t rr = lean_lcp(seq0, lane4, (uint32_t)(QB + q2), (uint32_t)(DB0 + q2 - 2 * k), (uint32_t)cap2);
+			q2 += (int)rr;
+			more = rr == 32u;
+		}
+		const uint32_t nv = (int)w >= 0 ? ((uint32_t)q2 << 16) | (w & 0xFFFFu) : w;
+		R[c] = nv;
+		{
+			const int key = (int)((nv & 0xFFFF0000u) + (uint32_t)ckd);
+			best_word = key > best_key ? nv : best_word;
+			best_key = max(best_key, key);
+		}
+	};
+	// cells c0 .. c0 + n - 1 are dead for every lane: written so, the running values stepped past them
+	auto skip_group = [&](auto c0c, auto nc) {
+		constexpr int c0 = decltype(c0c)::value, n = decltype(nc)::value;
+		prev = R[c0 + n - 1];
+		static_for<0, n>([&](auto jc) { R[c0 + decltype(jc)::value] = kLeanDead; });
+		Dk -= c17 * (uint32_t)n;
+		Bk += 2 * n;
+		rk += (uint32_t)n;
+		thrk += 0x10000 * n;
+	};
+	auto ckd_of = [](int d, int k) { return (int)((uint32_t)(-(k + 6 * d)) << 16) | (65535 - (d * 128 + k + 64)); };
+	auto level_end = [&]() { // T[d] = the best score so far; the ring moves on
+#pragma unroll
+		for (int x = 0; x + 1 < kGLag; x++)
+			Tr[x] = Tr[x + 1];
+		Tr[kGLag - 1] = best_key >> 16;
+	};
+	bool done = false, over = false;
+	bool in_range = set_range(1);
+	live = live && in_range;
+	static_for<1, kGUnrollLevels + 1>([&](auto dc) {
+		constexpr int d = decltype(dc)::value;
+		if (!done) {
+			if (__ballot(live) == 0ull) {
+				done = true;
+			} else {
+				level_start(d);
+				// groups of cells: straight code, then the (rare) longer slides of the group; a group no lane's bound lets
+				// live (the dead half of a side's last levels) is written dead without looking
+				static_for<0, (2 * d + 1 + kLeanGroup - 1) / kLeanGroup>([&](auto gc) {
+					constexpr int c0 = C - d + kLeanGroup * decltype(gc)::value;
+					constexpr int n = (C + d + 1 - c0) < kLeanGroup ? (C + d + 1 - c0) : kLeanGroup;
+					if (__ballot(lo1 <= c0 + n - 1 - C && lo1 + (int)width >= c0 - C) == 0ull) {
+						skip_group(std::integral_constant<int, c0>{}, std::integral_constant<int, n>{});
+					} else {
+						uint32_t r2[kLeanGroup] = {};
+						uint32_t any32 = 0;
+						static_for<0, n>([&](auto jc) {
+							constexpr int c = c0 + decltype(jc)::value;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, d - 1>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							any32 |= r2[decltype(jc)::value];
+						});
+						if (__ballot((any32 & 32u) != 0u) != 0ull) {
+							static_for<0, n>([&](auto jc) {
+								constexpr int c = c0 + decltype(jc)::value;
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							});
+						}
+					}
+				});
+				const bool some = set_range(d + 1);
+				live = (int)alldead >= 0 && some;
+				level_end();
+			}
+		}
+	});
+	for (int d = kGUnrollLevels + 1; !done && __ballot(live) != 0ull; d++) {
+		if (d > D) {
+			over = live;
+			break;
+		}
+		level_start(d);
+		// (the running values start at k = -d: cells left of it are skipped without a step)
+		static_for<0, (kCells - 2 + kLeanGroup - 1) / kLeanGroup>([&](auto gc) {
+			constexpr int c0 = 1 + decltype(gc)::value * kLeanGroup;
+			constexpr int n = (kCells - 1 - c0) < kLeanGroup ? (kCells - 1 - c0) : kLeanGroup;
+			if (!(c0 + n - 1 - C < -d || c0 - C > d)) {
+				if (c0 - C >= -d && c0 + n - 1 - C <= d) {
+					// the whole group lies inside the level: the same straight code as above
+					if (__ballot(lo1 <= c0 + n - 1 - C && lo1 + (int)width >= c0 - C) == 0ull) {
+						skip_group(std::integral_constant<int, c0>{}, std::integral_constant<int, n>{});
+					} else {
+						uint32_t r2[kLeanGroup] = {};
+						uint32_t any32 = 0;
+						static_for<0, n>([&](auto jc) {
+							constexpr int c = c0 + decltype(jc)::value;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, D>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							any32 |= r2[decltype(jc)::value];
+						});
+						if (__ballot((any32 & 32u) != 0u) != 0ull) {
+							static_for<0, n>([&](auto jc) {
+								constexpr int c = c0 + decltype(jc)::value;
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, c - C), r2[decltype(jc)::value]);
+							});
+						}
+					}
+				} else {
+					// a group the level's ends cut through: cell by cell
+					static_for<0, n>([&](auto jc) {
+						constexpr int c = c0 + decltype(jc)::value;
+						constexpr int k = c - C;
+						if (!(k < -d || k > d)) {
+							uint32_t r2 = 0;
+							cell(std::integral_constant<int, c>{}, std::integral_constant<int, D>{}, ckd_of(d, k), r2);
+							if (__ballot((r2 & 32u) != 0u) != 0ull)
+								slide_on(std::integral_constant<int, c>{}, ckd_of(d, k), r2);
+						}
+					});
+				}
+			}
+		});
+		const bool some = set_range(d + 1);
+		live = (int)alldead >= 0 && some;
+		level_end();
+	}
+	// the best cell: score, where, its statistics
+	const int s2 = best_key >> 16;
+	const int order = 65535 - (best_key & 65535);
+	const int bd = order >> 7, bk = (order & 127) - 64;
+	const int g1 = (int)((best_word >> 8) & 63u), g2 = g1 - bk;
+	out.i = (s2 + bk + 6 * bd) >> 1;
+	out.j = out.i - bk;
+	out.s2 = s2;
+	out.gopen = (int)(best_word & 63u);
+	out.mism = bd - (g1 + g2);
+	return over ? 1 : 0;
+}
+
 constexpr int kBlkItems = 2048; // HSPs a wavefront orders at a time
 constexpr int kKeyBuckets = 16;  // mismatches of the diagonal on one side of the seed run, capped at 15
 
@@ -1256,8 +1523,8 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__
 	}
 }
 
-template <int MAXL> struct RowsLds {
-	static constexpr int D = kGFastD;
+template <int MAXL, int DD = kGFastD> struct RowsLds {
+	static constexpr int D = DD;
 	static constexpr int kQ = MAXL / 16 + 4;                     // rows of a lane's read letters: right part, then left part reversed
 	static constexpr int kD = (MAXL + 2 * D + 32 + 60) / 16 + 3; // rows of its database letters, likewise
 	static constexpr int kRows = kLeanFrontRows + kQ + kD + 1;   // (one spare row behind: the last word's neighbour)
@@ -1280,12 +1547,11 @@ struct Pending {
 // One round of 64 HSPs, one per lane, both sides: the record once, the letters once (right part forward, left part
 // reversed, packed behind one another in the lane's column of the transposed rows), the lean rows left then right, the
 // finished hit over the record.  HSPs this tier cannot finish wait in the two front rows (`n_pend` table slots).
-template <int MAXL>
-__device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, pgx_hit *__restrict__ table, pgx_hit *hp, bool mine, Pending &pend,
+template <int MAXL, int D = kGFastD>
+__device__ __forceinline__ void gap_round(RowsLds<MAXL, D> &lds, const GapView &v, pgx_hit *__restrict__ table, pgx_hit *hp, bool mine, Pending &pend,
 					  const TierLists &tl)
 {
-	using Lds = RowsLds<MAXL>;
-	constexpr int D = kGFastD;
+	using Lds = RowsLds<MAXL, D>;
 	const int lane = threadIdx.x & 63;
 	const lds_word *seq0 = (const lds_word *)&lds.seq[0];
 	uint32_t *col = &lds.seq[lane]; // row r of this lane: col[r * 64]
@@ -1294,7 +1560,10 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, 
 	bool on = mine && a.L <= MAXL;
 	// (the seed stage's own estimate of the levels a side will run, floor((2 letters - B0) / 5): a side it puts two levels
 	// beyond this tier's D would run all D levels here only to be handed on)
-	on = on && (2 * a.qa - a.b0l) / 5 <= D + 1 && (2 * (a.L - a.qa) - a.b0r) / 5 <= D + 1;
+	// (not for the 40-difference rows: the seed stage follows the diagonal for 18 mismatches only, its estimate says
+	// nothing about sides beyond that -- half of a 500-base read's HSPs were handed on unseen)
+	if constexpr (D < kGLag)
+		on = on && (2 * a.qa - a.b0l) / 5 <= D + 1 && (2 * (a.L - a.qa) - a.b0r) / 5 <= D + 1;
 	if (on && a.s.ra) {
 		uint64_t any = 0;
 		for (int w = 0; w < (a.L + 31) / 32; w++)
@@ -1378,8 +1647,13 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, 
 		const int qa_ = (int)(geo & 1023u), L_ = (int)(geo >> 10);
 		const uint32_t off = side ? off_r : off_l;
 		Side r;
-		const int st = greedy_rows_lean<D>(seq0, (uint32_t)lane * 4u, on, (int)(off & 0xFFFFu), (int)(off >> 16), side ? L_ - qa_ : qa_,
-						   side ? slen - sa : sa, (int)(side ? (send_w >> 12) & 0x7FFu : (send_w >> 1) & 0x7FFu), r);
+		int st;
+		if constexpr (D >= kGLag)
+			st = greedy_rows_deep<D>(seq0, (uint32_t)lane * 4u, on, (int)(off & 0xFFFFu), (int)(off >> 16), side ? L_ - qa_ : qa_,
+						 side ? slen - sa : sa, (int)(side ? (send_w >> 12) & 0x7FFu : (send_w >> 1) & 0x7FFu), r);
+		else
+			st = greedy_rows_lean<D>(seq0, (uint32_t)lane * 4u, on, (int)(off & 0xFFFFu), (int)(off >> 16), side ? L_ - qa_ : qa_,
+						 side ? slen - sa : sa, (int)(side ? (send_w >> 12) & 0x7FFu : (send_w >> 1) & 0x7FFu), r);
 		worst = st == 1 || worst == 1 ? 1 : (st == 2 || worst == 2 ? 2 : 0);
 		if (side) {
 			rr = r;
@@ -1423,8 +1697,8 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL> &lds, const GapView &v, 
 	park(fail_b, pend.nb, 1, tl.b, tl.b_count);
 }
 
-template <int MAXL>
-__device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restrict__ table, Pending &pend, const TierLists &tl)
+template <int MAXL, int D = kGFastD>
+__device__ __forceinline__ void gap_flush(RowsLds<MAXL, D> &lds, pgx_hit *__restrict__ table, Pending &pend, const TierLists &tl)
 {
 	const int lane = threadIdx.x & 63;
 	list_append(lane < (int)pend.na, table + (lane < (int)pend.na ? lds.seq[lane] : 0u), tl.a, tl.a_count, tl.cap);
@@ -1434,11 +1708,11 @@ __device__ __forceinline__ void gap_flush(RowsLds<MAXL> &lds, pgx_hit *__restric
 }
 
 // the main table: rounds of 64 consecutive entries of the sorted slot list
-template <int MAXL, int WAVES>
+template <int MAXL, int WAVES, int D = kGFastD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_gapped_rows(GapView v, pgx_hit *__restrict__ table, const uint32_t *__restrict__ items,
 													  uint32_t *__restrict__ bins, TierLists tl)
 {
-	__shared__ RowsLds<MAXL> lds;
+	__shared__ RowsLds<MAXL, D> lds;
 	const int lane = threadIdx.x & 63;
 	const uint32_t n_items = bins[kTotalAt];
 	uint32_t *next_round = bins + kTotalAt + 1; // (zero at launch)
@@ -1459,10 +1733,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
 		for (uint32_t round = first; round < last; round++) {
 			const uint32_t idx = round * 64u + lane;
 			const bool mine = idx < n_items;
-			gap_round<MAXL>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, pend, tl);
+			gap_round<MAXL, D>(lds, v, table, table + items[mine ? idx : n_items - 1u], mine, pend, tl);
 		}
 	}
-	gap_flush<MAXL>(lds, table, pend, tl);
+	gap_flush<MAXL, D>(lds, table, pend, tl);
 }
 
 // The pool form, ONE pass (round 3): a wavefront takes the HSPs of 64 reads (FLAT: 2 048 entries of the overflow table),
@@ -1849,15 +2123,18 @@ struct DiagLds {
 
 __device__ __forceinline__ int dpp_from_lower(int v, int dead) { return __builtin_amdgcn_update_dpp(dead, v, 0x138, 0xf, 0xf, false); } // lane l <- lane l - 1
 __device__ __forceinline__ int dpp_from_upper(int v, int dead) { return __builtin_amdgcn_update_dpp(dead, v, 0x130, 0xf, 0xf, false); } // lane l <- lane l + 1
-// the wavefront's maximum, in every lane
+// the wavefront's maximum, in every lane.  v_max_i32 with a DPP operand (dst = src1 = v: a lane without a source, or in a
+// masked row, keeps v); a VALU write needs two wait states before a DPP read of the register
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false)); // row_shr:1
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false)); // row_shr:2
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false)); // row_shr:4
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false)); // row_shr:8  -> lane 15 of each row holds the row's maximum
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
-	v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+	asm volatile("s_nop 1\n\t"
+		     "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+		     "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+		     "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+		     "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" // lane 15 of each row: the row's maximum
+		     "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t" // into rows 1 and 3
+		     "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" // into rows 2 and 3: lane 63 holds the maximum
+		     : "+v"(v));
 	return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -2101,16 +2378,19 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	}
 	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
 	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's), [4] E (in A's)
-	// (long reads: every HSP goes straight to the wide kernels, which read list A)
-	const TierLists tl = { listA, long_reads ? listA : listB, cnt, long_reads ? cnt : cnt + 1, cap };
+	// (long reads: every HSP goes straight to the wide kernels, which read list A; reads of 321-512 bases: the first tier
+	// holds 40 differences a side with the full statistics, what it cannot finish goes to list A and the wide kernels too)
+	const bool deep = !long_reads && max_len > 320 && getenv("PGX_GAP_NODEEP") == nullptr;
+	const bool one_list = long_reads || deep;
+	const TierLists tl = { listA, one_list ? listA : listB, cnt, one_list ? cnt : cnt + 1, cap };
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
 	// the two tables; then the rows with the full statistics over what they listed (list A), which lists for the wider tiers (B)
-#define PGX_GAPPED_LAUNCH(ML, WV)                                                                                                              \
+#define PGX_GAPPED_LAUNCH(ML, WV, DD)                                                                                                          \
 	do {                                                                                                                                 \
 		v.key = main_key;                                                                                                            \
 		const unsigned grid_wv = std::min<unsigned>(grid, 256u * 4u * WV * 2u); /* two full rounds of resident wavefronts */  \
 		if (binned)                                                                                                                  \
-			hipLaunchKernelGGL((k_gapped_rows<ML, (WV > 4 ? 4 : WV)>), dim3(256u * 4u * (WV > 4 ? 4 : WV) * 2u), dim3(64), 0, stream, v, main_table, \
+			hipLaunchKernelGGL((k_gapped_rows<ML, (WV > 4 ? 4 : WV), DD>), dim3(256u * 4u * (WV > 4 ? 4 : WV) * 2u), dim3(64), 0, stream, v, main_table, \
 					   gw.items.data(), gw.bins.data(), tl);                                                                  \
 		else if (pools2)                                                                                                             \
 			hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
@@ -2127,30 +2407,32 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		else                                                                                                                         \
 			hipLaunchKernelGGL((k_gapped_pool<true, ML, (WV > 4 ? 4 : WV)>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,       \
 					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, tl, gw.order.data()); \
-		if (!long_reads)                                                                                                             \
+		if (!one_list)                                                                                                               \
 			hipLaunchKernelGGL((k_gapped_fast<2, ML, WV, kGFastD>), dim3(256 * 4 * WV), dim3(64), 0, stream, v,                      \
 					   reinterpret_cast<pgx_hit *>(listA), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, \
 					   reinterpret_cast<const unsigned long long *>(cnt), listB, cnt + 1, cap, gw.side_list.data(), 0, gw.order.data()); \
 	} while (0)
 	if (max_len <= 160)
-		PGX_GAPPED_LAUNCH(160, PGX_LEAN_WAVES);
+		PGX_GAPPED_LAUNCH(160, PGX_LEAN_WAVES, kGFastD);
 	else if (max_len <= 192)
-		PGX_GAPPED_LAUNCH(192, 4);
+		PGX_GAPPED_LAUNCH(192, 4, kGFastD);
 	else if (max_len <= 320)
-		PGX_GAPPED_LAUNCH(320, 3);
+		PGX_GAPPED_LAUNCH(320, 3, kGFastD);
+	else if (deep)
+		PGX_GAPPED_LAUNCH(512, 2, kGFastD2);
 	else
-		PGX_GAPPED_LAUNCH(512, 2);
+		PGX_GAPPED_LAUNCH(512, 2, kGFastD);
 #undef PGX_GAPPED_LAUNCH
 	// the wider tiers, each passing on what it cannot hold: the lane-per-HSP kernel with rows for 40 differences a side
 	// and the X-drop history (reads of <= 512 bases without ambiguity letters: most of what reads of 300-500 bases
 	// list), then one wavefront per HSP with rows for 62 differences, then for the spec's 1 000
-	if (!long_reads)
+	if (!one_list)
 		hipLaunchKernelGGL((k_gapped_fast<2, 512, 2, kGFastD2>), dim3(256 * 6 * 2), dim3(64), 0, stream, v,
 				   reinterpret_cast<pgx_hit *>(listB), (unsigned long long)cap, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
 				   reinterpret_cast<const unsigned long long *>(cnt + 1), listA, cnt + 2, cap,
 				   gw.side_list.data(), 0, gw.order.data());
 	// (list C, or list A itself for long reads) -> one lane per diagonal -> D -> the LDS rows for 62 differences -> E -> for 1 000
-	const uint32_t *c_diag = long_reads ? cnt : cnt + 2;
+	const uint32_t *c_diag = one_list ? cnt : cnt + 2;
 	static const bool no_diag = getenv("PGX_GAP_NODIAG") != nullptr; // (measurement aid: the wide kernels alone, as in round 2)
 	if (no_diag) {
 		hipLaunchKernelGGL(k_gapped_big<62>, dim3(256 * 32), dim3(64), 0, stream, v, (const unsigned long long *)listA, c_diag, cap, listB, cnt + 3);

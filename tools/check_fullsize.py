@@ -1,5 +1,6 @@
 """One-off deep check: N reads (default 200 000) of the bench stream at offset FIRST through the oracle chain on the host
-cores and through the fused GPU path; the -outfmt 6 tables and the consensus texts must be identical."""
+cores and through the fused GPU path; the -outfmt 6 tables and the consensus texts must be identical.
+env: N, FIRST, READ_LEN (default 150)."""
 import ctypes as C, hashlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +9,7 @@ from pangea_plus_amd import _capi
 from test_gpu_fullsize import OCfg, ORes
 pg.init(0)
 n = int(os.environ.get("N", "200000")); first = int(os.environ.get("FIRST", "1000000"))
-cfg = pg.SynthCfg.default()
+cfg = pg.SynthCfg.default(read_len=int(os.environ.get("READ_LEN", "150")))
 d = tempfile.mkdtemp()
 _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), d.encode()))
 pg.TaxDb.create(d)
