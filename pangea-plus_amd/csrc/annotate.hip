@@ -17,6 +17,10 @@
 #include "consensus_core.hpp"
 #include <mutex>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "engine.hpp"
 #include "taxdb.hpp"
@@ -672,10 +676,48 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	if (!db->bound)
 		return fail(PGX_E_ARG, "pgx_rdp_from_file: bind the database to a taxonomy first");
 	PGX_TRY(require_device());
-	bool ok;
-	std::string text = read_text_file(path, &ok);
-	if (!ok)
-		return fail(PGX_E_IO, "cannot open RDP file %s", path);
+	// the file's bytes where the page cache holds them (a private read-only mapping: the parsing threads below fault its
+	// pages in as they reach them; a copy through read() into a zero-filled string was 0.07 s of a 2 M-line file's 0.55 s);
+	// what cannot be mapped (a pipe, an empty file) is read
+	struct FileText {
+		const char *p = nullptr;
+		size_t n = 0;
+		void *map = nullptr;
+		std::string copy;
+		~FileText()
+		{
+			if (map)
+				munmap(map, n);
+		}
+		const char *data() const { return p; }
+		size_t size() const { return n; }
+		bool empty() const { return n == 0; }
+		char back() const { return p[n - 1]; }
+	} text;
+	{
+		const int fd = open(path, O_RDONLY);
+		if (fd < 0)
+			return fail(PGX_E_IO, "cannot open RDP file %s", path);
+		struct stat st;
+		if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+			void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+			if (m != MAP_FAILED) {
+				text.map = m;
+				text.p = (const char *)m;
+				text.n = (size_t)st.st_size;
+				madvise(m, text.n, MADV_WILLNEED);
+			}
+		}
+		close(fd);
+		if (!text.map) {
+			bool ok;
+			text.copy = read_text_file(path, &ok);
+			if (!ok)
+				return fail(PGX_E_IO, "cannot open RDP file %s", path);
+			text.p = text.copy.data();
+			text.n = text.copy.size();
+		}
+	}
 	const size_t n = (size_t)reads->n;
 	const bool trace = getenv("PGX_TRACE") != nullptr;
 	auto t_prev = std::chrono::steady_clock::now();
@@ -687,10 +729,8 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		t_prev = now;
 	};
 	lap("file read");
-	std::vector<uint32_t> off(n + 1, 0), name, trips(n ? n : 1, 0);
-	std::vector<int8_t> rank;
+	std::vector<uint32_t> off(n + 1, 0), trips(n ? n : 1, 0);
 	std::vector<uint8_t> present(n ? n : 1, 0);
-	std::vector<uint32_t> code;
 	// A line belongs to the first read at or after the cursor that carries its name (the streams are in the same
 	// order; names may repeat).  The reads are indexed by name hash so that a line of a read that is not in this
 	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.
@@ -698,13 +738,37 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	lap("name index");
 	static const char kFive[] = "\t\t\t\t\t";
 	const char *base = text.data();
-	// ---- lines
+	// ---- lines (all host cores: each takes a stretch of the text and notes the byte after every newline in it)
 	std::vector<size_t> ls; // start of every line, plus the end of the text
-	ls.reserve(text.size() / 64 + 2);
-	for (size_t s0 = 0; s0 < text.size();) {
-		ls.push_back(s0);
-		const char *nl = (const char *)memchr(base + s0, '\n', text.size() - s0);
-		s0 = nl ? (size_t)(nl - base) + 1 : text.size();
+	{
+		const unsigned tw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), text.size() / (1u << 20) + 1));
+		std::vector<std::vector<size_t>> part(tw);
+		std::vector<std::thread> th;
+		for (unsigned t = 0; t < tw; t++)
+			th.emplace_back([&, t]() {
+				const size_t c0 = text.size() * t / tw, c1 = text.size() * (t + 1) / tw;
+				std::vector<size_t> mine; // (the thread's own vector: see pass 2)
+				mine.reserve((c1 - c0) / 64 + 16);
+				for (size_t s0 = c0; s0 < c1;) {
+					const char *nl = (const char *)memchr(base + s0, '\n', c1 - s0);
+					if (!nl)
+						break;
+					s0 = (size_t)(nl - base) + 1;
+					if (s0 < text.size())
+						mine.push_back(s0);
+				}
+				part[t] = std::move(mine);
+			});
+		for (auto &x : th)
+			x.join();
+		size_t total = text.empty() ? 0 : 1;
+		for (auto &v : part)
+			total += v.size();
+		ls.reserve(total + 1);
+		if (!text.empty())
+			ls.push_back(0);
+		for (auto &v : part)
+			ls.insert(ls.end(), v.begin(), v.end());
 	}
 	const size_t n_lines = ls.size();
 	lap("line starts");
@@ -734,7 +798,18 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			const char *line;
 			size_t len;
 			line_of(i, &line, &len);
-			const char *five = (const char *)memmem(line, len, kFive, 5);
+			// (the first run of five tabs: from tab to tab -- the C library's memmem spends most of a 130-byte line setting up)
+			const char *five = nullptr;
+			for (const char *tb = (const char *)memchr(line, '\t', len); tb && (size_t)(tb - line) + 5 <= len;) {
+				size_t run = 1;
+				while (run < 5 && tb[run] == '\t')
+					run++;
+				if (run == 5) {
+					five = tb;
+					break;
+				}
+				tb = (const char *)memchr(tb + run, '\t', len - (size_t)(tb + run - line));
+			}
 			id_len[i] = (uint32_t)(five ? (size_t)(five - line) : len);
 			has_five[i] = five != nullptr;
 			if (index.unique)
@@ -823,15 +898,16 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	std::vector<std::vector<std::string>> t_local(hw); // per thread: its distinct cleaned names, by local number
 	parallel([&](unsigned t, size_t i0, size_t i1) {
 		std::unordered_map<std::string, uint32_t> lmap;
-		std::vector<std::string> &loc = t_local[t];
+		std::vector<std::string> loc;
 		// (names: a database with 33 000 genera filled a 65 536-slot table half way, after which every field took the
 		// interning lock: 0.9 s instead of 0.5 s for 2 M lines)
 		Memo names(1 << 12), ranks(1 << 8);
-		std::vector<uint32_t> &nm = t_name[t];
-		std::vector<int8_t> &rk = t_rank[t];
-		// (room for the usual seven triplets a line up front: growing the vectors by doubling made this pass SLOWER with
-		// more threads -- 0.27 s on one, 0.60 s on four -- every regrowth maps and unmaps tens of megabytes under the
-		// process's one address-space lock)
+		// (the thread's OWN vectors, moved into t_name / t_rank / t_local at the end: the headers of those sixteen vectors lie
+		// side by side in memory, and every push_back through a reference to one of them wrote its end pointer into a cache
+		// line that two other threads were writing theirs to -- this pass took 0.27 s on one thread, 0.60 s on four and
+		// 0.28 s on sixteen)
+		std::vector<uint32_t> nm;
+		std::vector<int8_t> rk;
 		nm.reserve((i1 - i0) * 8 + 64);
 		rk.reserve((i1 - i0) * 8 + 64);
 		for (size_t i = i0; i < i1; i++) {
@@ -891,39 +967,56 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 				fh = 1469598103934665603ull;
 			}
 		}
+		t_name[t] = std::move(nm);
+		t_rank[t] = std::move(rk);
+		t_local[t] = std::move(loc);
 	});
 	lap("pass 2 (fields)");
+	// the threads' pieces behind one another (matched reads come in increasing order, so the triplets already lie in read
+	// order): token ids for each thread's distinct names (the database's table, one thread), then every thread maps and
+	// copies its own piece into arrays that nobody zero-filled first
+	std::vector<std::vector<uint32_t>> tok_of(hw);
+	std::vector<size_t> piece_at(hw + 1, 0);
 	for (unsigned t = 0; t < hw; t++) {
-		std::vector<uint32_t> tok_of(t_local[t].size());
-		for (size_t k = 0; k < tok_of.size(); k++)
-			tok_of[k] = db->intern(t_local[t][k]);
-		for (auto &x : t_name[t])
-			x = tok_of[x];
-		name.insert(name.end(), t_name[t].begin(), t_name[t].end());
-		rank.insert(rank.end(), t_rank[t].begin(), t_rank[t].end());
+		tok_of[t].resize(t_local[t].size());
+		for (size_t k = 0; k < tok_of[t].size(); k++)
+			tok_of[t][k] = db->intern(t_local[t][k]);
+		piece_at[t + 1] = piece_at[t] + t_name[t].size();
 	}
+	const size_t n_trip = piece_at[hw];
+	std::unique_ptr<uint32_t[]> name_a(new uint32_t[n_trip + 1]), code_a(new uint32_t[n_trip + 1]);
+	std::unique_ptr<int8_t[]> rank_a(new int8_t[n_trip + 1]);
+	parallel([&](unsigned t, size_t, size_t) {
+		uint32_t *nm = name_a.get() + piece_at[t], *cd = code_a.get() + piece_at[t];
+		int8_t *rk = rank_a.get() + piece_at[t];
+		const std::vector<uint32_t> &src = t_name[t], &map = tok_of[t];
+		const std::vector<int8_t> &srk = t_rank[t];
+		for (size_t k = 0; k < src.size(); k++) {
+			const uint32_t tk = map[src[k]];
+			nm[k] = tk;
+			rk[k] = srk[k];
+			cd[k] = (tk << 3) | (uint32_t)(srk[k] + 1);
+		}
+	});
 	lap("concatenate");
-	// matched reads come in increasing order, so the triplets already lie in read order
-	code.resize(name.size());
-	for (size_t k = 0; k < name.size(); k++)
-		code[k] = (name[k] << 3) | (uint32_t)(rank[k] + 1);
-	for (size_t r = 0; r < n; r++)
-		off[r + 1] = off[r] + trips[r];
 	pgx_rdp *rd = new pgx_rdp();
 	rd->n = (int64_t)n;
 	rd->max_trip = 0;
-	for (size_t r = 0; r < n; r++)
+	for (size_t r = 0; r < n; r++) {
+		off[r + 1] = off[r] + trips[r];
 		rd->max_trip = std::max(rd->max_trip, (int)std::min<uint32_t>(trips[r], 8));
+	}
 	int rc = rd->d_off.alloc(n + 1);
 	if (rc == 0) rc = rd->d_off.upload(off.data(), n + 1);
-	if (rc == 0) rc = rd->d_name.alloc(name.size() ? name.size() : 1);
-	if (rc == 0) rc = rd->d_name.upload(name.data(), name.size());
-	if (rc == 0) rc = rd->d_rank.alloc(rank.size() ? rank.size() : 1);
-	if (rc == 0) rc = rd->d_rank.upload(rank.data(), rank.size());
-	if (rc == 0) rc = rd->d_code.alloc(code.size() ? code.size() : 1);
-	if (rc == 0) rc = rd->d_code.upload(code.data(), code.size());
+	if (rc == 0) rc = rd->d_name.alloc(n_trip ? n_trip : 1);
+	if (rc == 0) rc = rd->d_name.upload(name_a.get(), n_trip);
+	if (rc == 0) rc = rd->d_rank.alloc(n_trip ? n_trip : 1);
+	if (rc == 0) rc = rd->d_rank.upload(rank_a.get(), n_trip);
+	if (rc == 0) rc = rd->d_code.alloc(n_trip ? n_trip : 1);
+	if (rc == 0) rc = rd->d_code.upload(code_a.get(), n_trip);
 	if (rc == 0) rc = rd->d_present.alloc(present.size());
 	if (rc == 0) rc = rd->d_present.upload(present.data(), present.size());
+	lap("offsets, uploads");
 	if (rc < 0) {
 		delete rd;
 		return rc;

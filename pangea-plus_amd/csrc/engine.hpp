@@ -1,6 +1,9 @@
 // Internal object model of libpangea_hip: what lives in HBM for one process / one GPU.
 #pragma once
 #include <memory>
+#include <functional>
+#include <thread>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -168,22 +171,60 @@ struct ReadNameIndex {
 		slot.assign(cap, 0);
 		next.assign(n, 0);
 		hash.resize(n);
+		// All host cores (a 2 M-read batch took 0.08 s on one): the hashes, then the table by compare-and-swap on its slots.
+		// Names that do not repeat need no `next` chain, and any insertion order serves find(); the first repeated name
+		// (or two names with one 64-bit hash) ends the parallel build and the table is made again in read order.
+		const unsigned hw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1));
+		auto parallel = [&](const std::function<void(size_t, size_t)> &f) {
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < hw; t++)
+				th.emplace_back(f, n * t / hw, n * (t + 1) / hw);
+			for (auto &x : th)
+				x.join();
+		};
+		parallel([&](size_t i0, size_t i1) {
+			std::string tmp;
+			for (size_t i = i0; i < i1; i++) {
+				const char *p;
+				size_t len;
+				name_span(i, tmp, &p, &len);
+				hash[i] = fnv64_bytes(p, len);
+			}
+		});
+		std::atomic<bool> repeated(false);
+		uint32_t *slots = slot.data();
+		parallel([&](size_t i0, size_t i1) {
+			for (size_t i = i0; i < i1 && !repeated.load(std::memory_order_relaxed); i++) {
+				const uint64_t h = hash[i];
+				size_t k = (size_t)(h & mask);
+				for (;;) {
+					uint32_t cur = __atomic_load_n(&slots[k], __ATOMIC_RELAXED);
+					if (cur == 0) {
+						if (__atomic_compare_exchange_n(&slots[k], &cur, (uint32_t)i + 1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+							break;
+					}
+					if (hash[cur - 1] == h) {
+						repeated.store(true, std::memory_order_relaxed);
+						break;
+					}
+					k = (k + 1) & mask;
+				}
+			}
+		});
+		if (!repeated.load())
+			return;
+		unique = false;
+		slot.assign(cap, 0);
 		std::vector<uint32_t> last(cap, 0);
-		std::string tmp;
 		for (size_t i = 0; i < n; i++) {
-			const char *p;
-			size_t len;
-			name_span(i, tmp, &p, &len);
-			const uint64_t h = hash[i] = fnv64_bytes(p, len);
+			const uint64_t h = hash[i];
 			size_t k = (size_t)(h & mask);
 			while (slot[k] && hash[slot[k] - 1] != h)
 				k = (k + 1) & mask;
-			if (!slot[k]) {
+			if (!slot[k])
 				slot[k] = (uint32_t)i + 1;
-			} else {
+			else
 				next[last[k] - 1] = (uint32_t)i + 1;
-				unique = false; // (or two names with one 64-bit hash: the callers only lose a shortcut)
-			}
 			last[k] = (uint32_t)i + 1;
 		}
 	}
