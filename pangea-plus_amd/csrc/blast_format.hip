@@ -340,7 +340,7 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	if (!reads->synthetic) {
 		name_off.assign((size_t)reads->n + 1, 0);
 		for (int64_t r = 0; r < reads->n; r++) {
-			name_blob.append(*reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+			name_blob.append(reads->h_text->data() + reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
 			name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 		}
 	}
@@ -569,7 +569,7 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 		if (!reads->synthetic) {
 			name_off.assign((size_t)n + 1, 0);
 			for (int64_t r = 0; r < n; r++) {
-				name_blob.append(*reads->h_text, reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
+				name_blob.append(reads->h_text->data() + reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
 				name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 			}
 		}
@@ -772,7 +772,7 @@ int pgx_blastn_run(const pgx_blastn_opts *o)
 		if (a < b) {
 			// a batch whose hit table does not fit (2^32 slots, or HBM) is halved until it does: reads that hit
 			// tens of thousands of subjects each need small batches, ordinary reads take the whole piece
-			const auto text = std::make_shared<const std::string>(std::move(piece));
+			const auto text = std::make_shared<const TextBlob>(std::move(piece));
 			std::function<int(int64_t, int64_t)> run = [&](int64_t first, int64_t count) -> int {
 				pgx_reads *rd = nullptr;
 				pgx_hits *h = nullptr;

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include <sys/mman.h>
 
 namespace pgx {
 
@@ -81,6 +82,34 @@ char *Text::release_malloc(size_t *len) const
 	if (len)
 		*len = s.size();
 	return p;
+}
+
+TextBlob::~TextBlob()
+{
+	if (map)
+		munmap(map, n);
+}
+
+std::shared_ptr<const TextBlob> TextBlob::from_file(const char *path, bool *ok)
+{
+	const int fd = open(path, O_RDONLY);
+	if (fd >= 0) {
+		struct stat st;
+		if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+			void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+			if (m != MAP_FAILED) {
+				close(fd);
+				auto b = std::make_shared<TextBlob>();
+				b->map = m;
+				b->p = (const char *)m;
+				b->n = (size_t)st.st_size;
+				*ok = true;
+				return b;
+			}
+		}
+		close(fd);
+	}
+	return std::make_shared<const TextBlob>(read_text_file(path, ok)); // (pipes, empty files, what cannot be mapped)
 }
 
 std::string read_text_file(const char *path, bool *ok)

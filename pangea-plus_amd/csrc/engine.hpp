@@ -79,7 +79,7 @@ struct pgx_reads {
 	bool synthetic = false;
 	bool has_amb = false;
 	// names of file-built batches: first word of each header, kept as (offset, length) into the file's text
-	std::shared_ptr<const std::string> h_text; // may be shared by several batches cut from one piece of a file
+	std::shared_ptr<const pgx::TextBlob> h_text; // may be shared by several batches cut from one piece of a file
 	std::vector<uint64_t> name_off;
 	std::vector<uint32_t> name_len;
 	std::vector<uint32_t> h_len, h_woff;
@@ -272,7 +272,7 @@ int db_fold_amb_to_g(const pgx_db *src, pgx_db **out);
 int db_read_host(const char *prefix, pgx_db **out);
 int64_t fasta_count_records(const char *path);
 int64_t fasta_count_records_text(const char *base, size_t len, bool *at_line_start);
-int reads_from_fasta_text(std::shared_ptr<const std::string> text, int64_t first, int64_t count, bool fold_to_g,
+int reads_from_fasta_text(std::shared_ptr<const TextBlob> text, int64_t first, int64_t count, bool fold_to_g,
 			  std::vector<uint32_t> *amb_count, pgx_reads **out);
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);

@@ -1219,19 +1219,19 @@ int reads_from_fasta_ex(const char *path, int64_t first, int64_t count, bool fol
 	};
 	const auto t_begin = now();
 	bool ok;
-	std::string text = read_text_file(path, &ok);
+	std::shared_ptr<const TextBlob> text = TextBlob::from_file(path, &ok);
 	if (!ok)
 		return fail(PGX_E_IO, "cannot open query file %s", path);
 	if (trace)
 		fprintf(stderr, "[pgx trace] reads_from_fasta: file %.1f ms\n", ms(t_begin, now()));
-	return reads_from_fasta_text(std::make_shared<const std::string>(std::move(text)), first, count, fold_to_g, amb_count, out);
+	return reads_from_fasta_text(std::move(text), first, count, fold_to_g, amb_count, out);
 }
 
 // the same for FASTA text already in memory (pgx_blastn_run streams large query files through this in pieces)
-int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t first, int64_t count, bool fold_to_g,
+int reads_from_fasta_text(std::shared_ptr<const TextBlob> text_ptr, int64_t first, int64_t count, bool fold_to_g,
 			  std::vector<uint32_t> *amb_count, pgx_reads **out)
 {
-	const std::string &text = *text_ptr;
+	const TextBlob &text = *text_ptr;
 	PGX_TRY(require_device());
 	const bool trace = getenv("PGX_TRACE") != nullptr;
 	auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1253,7 +1253,7 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 		}
 		rec_off.assign(df.let_off.begin(), df.let_off.end());
 	} else {
-		split_fasta_text(text, fl);
+		split_fasta_text(std::string(text.data(), text.size()), fl); // (4 GiB and more: the host splitter works on a string)
 		rec_off = fl.off;
 	}
 	const auto t_split = now();
@@ -1304,7 +1304,7 @@ int reads_from_fasta_text(std::shared_ptr<const std::string> text_ptr, int64_t f
 		d_letters_ptr = df.d_letters.data() + l0;
 		rd->h_text = text_ptr; // names are read from the text on demand
 	} else {
-		rd->h_text = std::make_shared<const std::string>(std::move(own_names));
+		rd->h_text = std::make_shared<const TextBlob>(std::move(own_names));
 		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1, 0, 16);
 		if (rc == 0) rc = d_letters_host.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
 		d_letters_ptr = d_letters_host.data();
@@ -1435,7 +1435,7 @@ std::string pgx_reads::name_of(int64_t i) const
 {
 	if (synthetic)
 		return "r" + std::to_string(first + i);
-	return h_text->substr(name_off[(size_t)i], name_len[(size_t)i]);
+	return std::string(h_text->data() + name_off[(size_t)i], name_len[(size_t)i]);
 }
 
 namespace pgx {
@@ -1619,7 +1619,7 @@ int pgx_reads_from_fasta_text(const char *text, size_t len, int64_t first, int64
 {
 	if ((!text && len) || !out)
 		return fail(PGX_E_ARG, "pgx_reads_from_fasta_text: null argument");
-	return pgx::reads_from_fasta_text(std::make_shared<const std::string>(text ? text : "", len), first, count, false, nullptr, out);
+	return pgx::reads_from_fasta_text(std::make_shared<const pgx::TextBlob>(std::string(text ? text : "", len)), first, count, false, nullptr, out);
 }
 
 // A batch back as FASTA text (">name" + one sequence line per read): the hand-over file between Trim and Classify
