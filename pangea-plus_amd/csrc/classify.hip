@@ -663,7 +663,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 					kr = (2 * (L - anchor) - b0r) / 5;
 					kl = kl < 14 ? kl : 14;
 					kr = kr < 14 ? kr : 14;
-					if (L > 320) {
+					if (L > db.deep_from) {
 						// reads the gapped stage runs with 40 differences a side (gapped.hip: greedy_rows_deep): B0 says nothing
 						// beyond 18 mismatches, and half the sides of a 500-base read at 7 % hold more.  Its rounds are ordered by
 						// the diagonal's own mismatch count, three levels to a step, plus the ~10 levels a side runs on past an
@@ -1757,6 +1757,7 @@ static DbView db_view(const pgx_db *db)
 	v.n_bases = db->n_bases;
 	v.bits = db->index_bits;
 	v.gapped = db->ungapped ? 0 : 1;
+	v.deep_from = gapped_deep_from();
 	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0;
 	return v;
 }

@@ -324,6 +324,7 @@ struct DbView {
 	int64_t n_bases; // letters of all subjects (the packed words hold 768 zero letters in front and behind)
 	int bits;
 	int gapped;   // spec v2: the seed stage hands over initial HSPs (score field = offset of the seed run in the HSP) to gapped.hip
+	int deep_from; // reads longer than this run the gapped stage's 40-difference rows (their ordering key counts mismatches)
 	int dbg_stop; // profiling aid (PGX_SEED_STOP): 1 = probes only, 2 = + postings/filter, 3 = + queue without diagonal work
 };
 
@@ -353,6 +354,16 @@ struct GappedWork {
 int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, const uint8_t *main_key, const uint32_t *read_start,
 		 const uint32_t *read_cnt, pgx_hit *ovf_table, const uint8_t *ovf_key, const unsigned long long *ovf_count, unsigned long long ovf_cap, bool long_reads,
 		 unsigned long long hit_cap, int max_len, GappedWork &gw, hipStream_t stream, const unsigned long long *main_used, const uint8_t *main_reg);
+// reads longer than this many bases run the gapped stage's rows for 40 differences a side (PGX_GAP_DEEP_FROM: measurement aid)
+inline int gapped_deep_from()
+{
+	static const int v = [] {
+		const char *e = getenv("PGX_GAP_DEEP_FROM");
+		const int x = e ? atoi(e) : 320;
+		return x < 192 ? 192 : (x > 320 ? 320 : x);
+	}();
+	return v;
+}
 // the main table's HSPs are handled region by region of the database (at most 240 regions: positions >> this)
 inline int gapped_region_shift(int64_t n_bases)
 {

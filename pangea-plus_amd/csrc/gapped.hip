@@ -2380,7 +2380,7 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's), [4] E (in A's)
 	// (long reads: every HSP goes straight to the wide kernels, which read list A; reads of 321-512 bases: the first tier
 	// holds 40 differences a side with the full statistics, what it cannot finish goes to list A and the wide kernels too)
-	const bool deep = !long_reads && max_len > 320 && getenv("PGX_GAP_NODEEP") == nullptr;
+	const bool deep = !long_reads && max_len > gapped_deep_from() && getenv("PGX_GAP_NODEEP") == nullptr;
 	const bool one_list = long_reads || deep;
 	const TierLists tl = { listA, one_list ? listA : listB, cnt, one_list ? cnt : cnt + 1, cap };
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
@@ -2416,6 +2416,8 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		PGX_GAPPED_LAUNCH(160, PGX_LEAN_WAVES, kGFastD);
 	else if (max_len <= 192)
 		PGX_GAPPED_LAUNCH(192, 4, kGFastD);
+	else if (max_len <= 320 && deep)
+		PGX_GAPPED_LAUNCH(320, 2, kGFastD2);
 	else if (max_len <= 320)
 		PGX_GAPPED_LAUNCH(320, 3, kGFastD);
 	else if (deep)
