@@ -777,3 +777,49 @@ def test_long_queries_that_overhang_the_first_and_the_last_subject(pg, oracle_bi
     assert {r.split("\t")[0] for r in rows} >= {"o0", "o1", "o2", "o3", "o4", "o5"}
     assert any(r.split("\t")[5] != "0" for r in rows if r.startswith(("o0", "o1", "o2", "o3")))  # gapped rows among them
     assert _blast_text(pg, db, rd, tmp_path, "ends") == want.read_bytes()
+
+
+def test_long_queries_whose_gaps_drift_off_the_diagonal_lanes(pg, oracle_bin, tmp_path):
+    """The one-lane-per-diagonal kernel (k_gapped_diag) holds diagonals -32 .. 31 of the anchor's and six-bit counts of gap
+    columns / openings.  Queries of 900-1 600 bases whose gaps all lean one way -- five to nine deletions (or insertions) of
+    6-9 bases, 120+ matching bases apart, so that each is crossed -- drift 40-70 diagonals and hold up to ~80 gap columns:
+    those HSPs must come out of the LDS-row kernels behind it, and the table must still be the oracle's."""
+    import random
+    rng = random.Random(4242)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))  # noqa: E731
+    rc = lambda s: "".join(comp[c] for c in reversed(s))  # noqa: E731
+    subjects = [rnd(rng.choice([1700, 2000])) for _ in range(24)]
+    db = tmp_path / "drift.fa"
+    db.write_text("".join(">gi|%d|x|d%d|\n%s\n" % (i + 1, i, s) for i, s in enumerate(subjects)))
+    reads = []
+    for i in range(96):
+        s = subjects[i % len(subjects)]
+        L = rng.choice([900, 1200, 1600])
+        o = rng.randrange(0, len(s) - L)
+        w = list(s[o:o + L])
+        n_gaps = rng.choice([5, 6, 7, 8, 9])
+        kind = i % 3                      # 0: deletions only, 1: insertions only, 2: alternating (no drift: stays with the lanes)
+        step = (L - 100) // (n_gaps + 1)
+        for g in range(n_gaps, 0, -1):    # from the far end, so earlier positions stay valid
+            p_ = 50 + g * step + rng.randrange(-10, 10)
+            n = rng.choice([6, 7, 8, 9])
+            if kind == 0 or (kind == 2 and g % 2):
+                del w[p_:p_ + n]
+            else:
+                w[p_:p_] = list(rnd(n))
+        for p_ in rng.sample(range(len(w)), len(w) // 60):
+            w[p_] = rng.choice("ACGT")
+        w = "".join(w)
+        reads.append(">q%d\n%s\n" % (i, rc(w) if i % 2 else w))
+    rd = tmp_path / "drift_reads.fa"
+    rd.write_text("".join(reads))
+    want = tmp_path / "drift_oracle.tsv"
+    assert run_cmd([oracle_bin, "blastn", "-query", str(rd), "-db", str(db), "-outfmt", "6", "-out", str(want), "-num_threads", "8"],
+                   timeout=900)[0] == 0
+    rows = [r.split(b"\t") for r in want.read_bytes().splitlines()]
+    # rows that cross many gaps one way: alignment lengths on query and subject differ by the drift
+    drift = [abs((int(r[7]) - int(r[6])) - abs(int(r[9]) - int(r[8]))) for r in rows]
+    assert max(drift) >= 40 and sum(d >= 33 for d in drift) >= 10
+    assert max(int(r[5]) for r in rows) >= 5
+    assert _blast_text(pg, db, rd, tmp_path, "drift") == want.read_bytes()
