@@ -2103,7 +2103,7 @@ __global__ __launch_bounds__(64) void k_gapped_big(GapView v, const unsigned lon
 //   is stored AS THE PRIORITY of the column that made it (1: from k - 1, a gap in the subject row; 0: from k + 1, a gap in
 //   the query row; 2: none -- a mismatch column, or letters matched after the gap), so "this gap column continues the
 //   parent's open gap" is one XOR of two fields of the winning parent's word.  Mismatches = d - gap columns, gap columns in
-//   the query row = G1 - k.  A field that nears 62 hands the HSP on.
+//   the query row = G1 - k.  A count that reaches 56 (looked at every eighth level) hands the HSP on.
 //   best cell: every lane keeps the best of ITS diagonal (score << 10 | 1023 - d: first d among equal scores) and the word
 //   of that cell; one reduction at the end of the side picks the first lane among the best.  The X-drop history T[d] (best
 //   score within d differences) needs the wave's maximum per level: six DPP steps; T itself lies across the lanes of one
@@ -2208,7 +2208,7 @@ __device__ __forceinline__ int diag_side(const lds_word *seq0, int M, int N, Sid
 		int q2 = (int)(w >> 16) + (int)r2; // 2 i (m3 >= 0 where it counts)
 		bool more = ok && r2 == 32u;
 		const bool slid = r2 != 0u;
-		while (__ballot(more) != 0ull) {
+		while (__builtin_amdgcn_ballot_w64(more) != 0ull) { // (the builtin: __ballot went through a select and a compare here)
 			if (more) {
 				const int c2 = E - (QB + q2);
 				if (c2 <= 0) {
@@ -2229,16 +2229,24 @@ __device__ __forceinline__ int diag_side(const lds_word *seq0, int M, int N, Sid
 			lane_word = nv;
 		}
 		R = nv;
-		const unsigned long long am = __ballot(nv >= 0);
+		const unsigned long long am = __builtin_amdgcn_ballot_w64(nv >= 0);
 		if (am == 0ull)
 			break;
 		// live cells at the wavefront's ends, or a statistics field about to overflow: the wide kernel takes the HSP
-		const bool near_full = nv >= 0 && ((((uint32_t)nv & 0x3F3Fu) + 0x0202u) & 0x4040u) != 0u;
-		if ((am & 0x8000000000000001ull) != 0ull || __ballot(near_full) != 0ull) {
+		// (the counts grow by at most one a level: looked at every eighth level, handed on from 56)
+		if ((am & 0x8000000000000001ull) != 0ull) {
 			status = 1;
 			break;
 		}
-		best = max(best, wave_max_i32(nv >= 0 ? s2 : (int)0x80000000u));
+		if ((d & 7) == 0) {
+			const bool near_full = nv >= 0 && ((((uint32_t)nv & 0x3F3Fu) + 0x0808u) & 0x4040u) != 0u;
+			if (__builtin_amdgcn_ballot_w64(near_full) != 0ull) {
+				status = 1;
+				break;
+			}
+		}
+		// (every live key of the level carries the same 1023 - d below the score: the largest key holds the largest score)
+		best = max(best, wave_max_i32(key) >> 10);
 		T = lane == (d & 63) ? best : T;
 	}
 	if (status)
