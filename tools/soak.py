@@ -31,3 +31,31 @@ for it in range(24):
     print("call %2d first=%8d  %s  free HBM %.2f GB" % (it, first, dg[:20], free / 1e9), flush=True)
     del reads, rdp
 print("soak ok")
+
+# ---- the file-to-file leg (mapped FASTA text, RDP import with its work arrays freed on a thread of their own): results
+# repeat, free HBM and the process's resident memory do not creep
+import resource
+def rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * resource.getpagesize() / 1e6
+m = 500_000
+seen = {}
+rss0 = None
+for it in range(12):
+    first = (it % 3) * m
+    fa, rf, out = os.path.join(d, "soak.fa"), os.path.join(d, "soak_rdp.txt"), os.path.join(d, "soak_out.txt")
+    reads = pg.Reads.from_synth(cfg, first, m); rdp = pg.Rdp.from_synth(cfg, first, m, db)
+    reads.write_fasta(fa); rdp.write_file(rf, reads, db)
+    del reads, rdp
+    r = pg.Reads.from_fasta(fa); p = pg.Rdp.from_file(rf, r, db)
+    hits, recs = _capi.classify_consensus(db, r, p)
+    _capi.consensus_format_file(db, r, hits, recs, out)
+    dg = hashlib.md5(open(out, "rb").read()).hexdigest()
+    assert seen.setdefault(first, dg) == dg, (it, first)
+    del r, p, hits, recs
+    free, total = torch.cuda.mem_get_info()
+    if it == 5:
+        rss0 = rss_mb()
+    print("file call %2d first=%8d  %s  free HBM %.2f GB  rss %.0f MB" % (it, first, dg[:12], free / 1e9, rss_mb()), flush=True)
+assert rss_mb() < rss0 + 300, (rss0, rss_mb())
+print("file soak ok")
