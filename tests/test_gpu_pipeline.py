@@ -264,3 +264,71 @@ def test_batch_written_as_files_reads_back_the_same(pg, chain, tmp_path):
     p3 = pg.Rdp.from_file(str(tmp_path / "rdp_mixed.txt"), r2, db)
     h3, c3 = _capi.classify_consensus(db, r2, p3)
     assert (c3["hit"][100] == -2) and (np.delete(c3, 100) == np.delete(c2, 100)).all()
+
+
+def test_rdp_text_in_odd_shapes_parses_as_the_oracle_reads_it(pg, chain, tmp_path, oracle_bin):
+    """The RDP import (mapped file, lines and fields on all host cores) against the checker's sequential reading of the same
+    text (oracle `consensus`, itself pinned by the reference Perl's goldens): no newline at the end of the file, lines
+    without the five-tab group, seven tabs in a row, a second five-tab group, trailing tabs, a single-field tail.  Lines
+    that name no read of the batch (the reference's walk never gets past one: "not found" to the end of the table) are
+    this library's own rule -- skipped, one probe each -- and must leave the result as if they were not there."""
+    from pangea_plus_amd import _capi
+    rows = (chain / "rdp.tsv").read_text().splitlines()
+    assert len(rows) >= 2000
+
+    def build(foreign):
+        out = []
+        for i, r in enumerate(rows):
+            rid, rest = r.split("\t\t\t\t\t", 1)
+            f = rest.split("\t")
+            k = i % 16
+            if k == 1:
+                out.append(rid)                                            # the id alone
+            elif k == 2:
+                out.append(rid + "\t\t\t\t\t\t\t" + rest)                  # seven tabs: two empty fields in front
+            elif k == 3:
+                out.append(rid + "\t\t\t\t\t" + rest + "\t\t\t\t\t" + rest)  # a second five-tab group ends the fields
+            elif k == 4:
+                out.append(rid + "\t\t\t\t\t" + rest + "\t\t\t")           # trailing tabs
+            elif k == 6:
+                out.append(rid + "\t\t\t\t\t" + "\t".join(f[:4]))          # the second triplet cut after its name
+            elif k == 5 and foreign:
+                out += ["", r]                                             # an empty line
+            elif k == 7 and foreign:
+                out += ["nobody_%d\t\t\t\t\t%s" % (i, rest), r]             # a read that does not exist
+            elif k == 8 and foreign:
+                out += [rid + "\tx\t\t\t\t\t" + rest, r]                   # a tab inside what stands before the five tabs
+            elif k == 9 and foreign:
+                out += [rid + "x\t\t\t\t" + rest, r]                       # four tabs only: the whole line is the id
+            else:
+                out.append(r)
+        return "\n".join(out)                                             # and no newline at the very end
+
+    (tmp_path / "odd.tsv").write_text(build(False))
+    (tmp_path / "odd_foreign.tsv").write_text(build(True))
+    assert run_cmd([oracle_bin, "consensus", "-b", str(chain / "hits_class.tsv"), "-r", str(tmp_path / "odd.tsv"),
+                    "-o", str(tmp_path / "consensus.txt")], timeout=600)[0] == 0
+    want = (tmp_path / "consensus.txt").read_bytes()
+    assert want != (chain / "consensus.txt").read_bytes() and len(want) > 10000
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
+    reads = pg.Reads.from_fasta(str(chain / "reads.fa"))
+    try:
+        for threads in ("1", "3", None):
+            if threads:
+                os.environ["PGX_RDP_THREADS"] = threads
+            else:
+                os.environ.pop("PGX_RDP_THREADS", None)
+            for name in ("odd.tsv", "odd_foreign.tsv"):
+                rdp = pg.Rdp.from_file(str(tmp_path / name), reads, db)
+                hits, recs = _capi.classify_consensus(db, reads, rdp)
+                assert _capi.consensus_format(db, reads, hits, recs) == want, (threads, name)
+    finally:
+        os.environ.pop("PGX_RDP_THREADS", None)
+    # an empty file and a file of newlines: no read has a line
+    for name, body in (("empty.tsv", ""), ("newlines.tsv", "\n\n\n")):
+        (tmp_path / name).write_text(body)
+        rdp = pg.Rdp.from_file(str(tmp_path / name), reads, db)
+        hits, recs = _capi.classify_consensus(db, reads, rdp)
+        assert (recs["hit"] == -2).all()
