@@ -1330,7 +1330,7 @@ constexpr int kGapBins = 256;
 // [kTotalAt] entries in all, [kTileAt + r] tiles before region r (one more: all tiles), [kSegAt + r * 256 + b] entries
 // (then cursor) of key byte b within region r
 constexpr int kBaseAt = 256, kCurAt = 512, kTotalAt = 768, kTileAt = 1024, kSegAt = 2048, kBinsWords = kSegAt + 256 * kGapBins + 16;
-constexpr int kSegTile = 16384; // entries a block sorts at a time in the second pass
+constexpr int kSegTile = 8192; // entries a block sorts at a time in the second pass (its LDS copy: 40 KB)
 
 // valid slots per database region (key byte 0xFF: no record in the slot)
 __global__ __launch_bounds__(256) void k_reg_hist(const uint8_t *__restrict__ key, const uint8_t *__restrict__ reg, const unsigned long long *__restrict__ used,
@@ -1371,18 +1371,47 @@ __global__ __launch_bounds__(256) void k_reg_bases(uint32_t *__restrict__ bins)
 	}
 }
 
-// first pass: slot numbers (and their key bytes) by region
+// exclusive prefix sums of the 256 counts of a block's histogram (256 threads: thread t owns h[t]); wsum: 4 words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *wsum)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(inc, o);
+		if (lane >= o)
+			inc += t;
+	}
+	if (lane == 63)
+		wsum[wave] = inc;
+	__syncthreads();
+	uint32_t off = 0;
+	for (int w = 0; w < wave; w++)
+		off += wsum[w];
+	return off + inc - v;
+}
+
+// first pass: slot numbers (and their key bytes) by region.  A tile of 8 192 slots is ordered by region IN LDS first (the
+// rank inside (tile, region) is what the counting atomic returns) and written out run by run: a region's ~34 entries of a
+// tile go out as 136 + 34 contiguous bytes.  Scattered straight from the registers every entry was two L2 requests of its
+// own -- 31 requests per read, 0.77 of what the L2s take per second: the pass was bound by its request count, 1.49 ms for
+// 2.4 GB (profiles/r03_c_pmc.txt).
+constexpr int kRegTile = 8192;
 __global__ __launch_bounds__(256) void k_reg_scatter(const uint8_t *__restrict__ key, const uint8_t *__restrict__ reg, const unsigned long long *__restrict__ used,
 						     unsigned long long cap, uint32_t *__restrict__ bins, uint32_t *__restrict__ items1, uint8_t *__restrict__ keys1)
 {
-	__shared__ uint32_t h[256], at[256];
+	__shared__ uint32_t h[256], loc[256], at[256], wsum[4];
+	__shared__ uint32_t s_item[kRegTile];
+	__shared__ uint8_t s_key[kRegTile], s_reg[kRegTile];
 	const unsigned long long n = *used < cap ? *used : cap;
-	for (unsigned long long t0 = (unsigned long long)blockIdx.x * (256 * 64); t0 < n; t0 += (unsigned long long)gridDim.x * (256 * 64)) {
+	constexpr int kQ = kRegTile / (256 * 16); // 16-byte words of keys per thread
+	for (unsigned long long t0 = (unsigned long long)blockIdx.x * kRegTile; t0 < n; t0 += (unsigned long long)gridDim.x * kRegTile) {
 		h[threadIdx.x] = 0;
 		__syncthreads();
-		uint4 kk[4], rr[4];
+		uint4 kk[kQ], rr[kQ];
+		uint32_t rk[kQ][8]; // ranks inside (tile, region), two to a word (< 8 192)
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
+		for (int q = 0; q < kQ; q++) {
 			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
 			kk[q] = base < n ? *reinterpret_cast<const uint4 *>(key + base) : make_uint4(~0u, ~0u, ~0u, ~0u);
 			rr[q] = base < n ? *reinterpret_cast<const uint4 *>(reg + base) : make_uint4(0u, 0u, 0u, 0u);
@@ -1390,26 +1419,42 @@ __global__ __launch_bounds__(256) void k_reg_scatter(const uint8_t *__restrict__
 #pragma unroll
 			for (int j = 0; j < 16; j++) {
 				const uint32_t b = (kw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+				uint32_t rank = 0;
 				if (b != 0xFFu && base + j < n)
-					atomicAdd(&h[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
+					rank = atomicAdd(&h[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
+				if (j & 1)
+					rk[q][j >> 1] |= rank << 16;
+				else
+					rk[q][j >> 1] = rank;
 			}
 		}
 		__syncthreads();
-		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kCurAt + threadIdx.x], h[threadIdx.x]) : 0u;
+		const uint32_t mine = h[threadIdx.x];
+		loc[threadIdx.x] = block_excl_scan_256(mine, wsum);
+		at[threadIdx.x] = mine ? atomicAdd(&bins[kCurAt + threadIdx.x], mine) : 0u;
 		__syncthreads();
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
+		for (int q = 0; q < kQ; q++) {
 			const unsigned long long base = t0 + ((unsigned long long)q * 256 + threadIdx.x) * 16;
 			const uint32_t kw[4] = { kk[q].x, kk[q].y, kk[q].z, kk[q].w }, rw[4] = { rr[q].x, rr[q].y, rr[q].z, rr[q].w };
 #pragma unroll
 			for (int j = 0; j < 16; j++) {
 				const uint32_t b = (kw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
 				if (b != 0xFFu && base + j < n) {
-					const uint32_t pos = atomicAdd(&at[(rw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
-					items1[pos] = (uint32_t)(base + j);
-					keys1[pos] = (uint8_t)b;
+					const uint32_t r = (rw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+					const uint32_t p = loc[r] + ((rk[q][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+					s_item[p] = (uint32_t)(base + j);
+					s_key[p] = (uint8_t)b;
+					s_reg[p] = (uint8_t)r;
 				}
 			}
+		}
+		__syncthreads();
+		const uint32_t total = loc[255] + h[255];
+		for (uint32_t p = threadIdx.x; p < total; p += 256) {
+			const uint32_t r = s_reg[p], d = at[r] + (p - loc[r]);
+			items1[d] = s_item[p];
+			keys1[d] = s_key[p];
 		}
 		__syncthreads();
 	}
@@ -1486,7 +1531,10 @@ __global__ __launch_bounds__(256) void k_seg_bases(uint32_t *__restrict__ bins)
 __global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__ keys1, const uint32_t *__restrict__ items1, uint32_t *__restrict__ bins,
 						     uint32_t *__restrict__ items2)
 {
-	__shared__ uint32_t h[256], at[256];
+	// (as k_reg_scatter: the tile ordered by key byte in LDS, written out run by run)
+	__shared__ uint32_t h[256], loc[256], at[256], wsum[4];
+	__shared__ uint32_t s_item[kSegTile];
+	__shared__ uint8_t s_b[kSegTile];
 	for (uint32_t tile = blockIdx.x;; tile += gridDim.x) {
 		uint32_t r, lo, hi;
 		if (!seg_tile(bins, tile, r, lo, hi))
@@ -1494,18 +1542,26 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__
 		h[threadIdx.x] = 0;
 		__syncthreads();
 		constexpr int kSteps = kSegTile / 1024 + 1; // (a tile that starts inside a word reaches one step further)
-		uint32_t kw[kSteps];
+		uint32_t kw[kSteps], rk[kSteps][2];
 #pragma unroll
 		for (int q = 0; q < kSteps; q++) {
 			const uint32_t i0 = (lo & ~3u) + 4u * threadIdx.x + 1024u * q;
 			kw[q] = i0 < hi ? *reinterpret_cast<const uint32_t *>(keys1 + i0) : 0u;
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+			for (int j = 0; j < 4; j++) {
+				uint32_t rank = 0;
 				if (i0 + j >= lo && i0 + j < hi)
-					atomicAdd(&h[(kw[q] >> (8 * j)) & 0xFFu], 1u);
+					rank = atomicAdd(&h[(kw[q] >> (8 * j)) & 0xFFu], 1u);
+				if (j & 1)
+					rk[q][j >> 1] |= rank << 16;
+				else
+					rk[q][j >> 1] = rank;
+			}
 		}
 		__syncthreads();
-		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], h[threadIdx.x]) : 0u;
+		const uint32_t mine = h[threadIdx.x];
+		loc[threadIdx.x] = block_excl_scan_256(mine, wsum);
+		at[threadIdx.x] = mine ? atomicAdd(&bins[kSegAt + r * 256 + threadIdx.x], mine) : 0u;
 		__syncthreads();
 #pragma unroll
 		for (int q = 0; q < kSteps; q++) {
@@ -1515,9 +1571,19 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const uint8_t *__restrict__
 				const uint32_t iv[4] = { it.x, it.y, it.z, it.w };
 #pragma unroll
 				for (int j = 0; j < 4; j++)
-					if (i0 + j >= lo && i0 + j < hi)
-						items2[atomicAdd(&at[(kw[q] >> (8 * j)) & 0xFFu], 1u)] = iv[j];
+					if (i0 + j >= lo && i0 + j < hi) {
+						const uint32_t b = (kw[q] >> (8 * j)) & 0xFFu;
+						const uint32_t p = loc[b] + ((rk[q][j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
+						s_item[p] = iv[j];
+						s_b[p] = (uint8_t)b;
+					}
 			}
+		}
+		__syncthreads();
+		const uint32_t total = hi - lo;
+		for (uint32_t p = threadIdx.x; p < total; p += 256) {
+			const uint32_t b = s_b[p];
+			items2[at[b] + (p - loc[b])] = s_item[p];
 		}
 		__syncthreads();
 	}
