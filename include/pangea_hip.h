@@ -39,9 +39,12 @@ typedef enum {
 
 const char *pgx_last_error(void);
 const char *pgx_version(void);
-/* Select the HIP device for the calling process (one process per GPU). */
+/* Select the HIP device for the calling process (one process per GPU): what `mpirun -np N` placing one mpiblastn rank
+ * per node does in the reference's job file (Scripts/submit_MPI-blast.job:8,24).  Without a call the process uses
+ * device $PGX_DEVICE, else device 0.  Every host thread that later enters the library is bound to that device. */
 int pgx_init(int device);
 int pgx_device_count(void);
+int pgx_current_device(void); /* the device this process is bound to, -1 before the first compute call / pgx_init */
 
 /* ------------------------------------------------------------------------------------------
  * Sequence database  —  `makeblastdb -in nt -out nt -dbtype nucl` (README.md:62) and
@@ -361,7 +364,8 @@ int pgx_probe_gather(uint64_t table_bytes, int stream, double *lines_per_s, doub
  * mix, one instruction kind at a time (kinds 0..7: see csrc/probe.hip), with
  * `waves_per_simd` (1..8) resident wavefronts.  out[0] = vector wave-instructions per second per SIMD, out[1] = shader
  * cycles per vector instruction of one wavefront, out[2] = kernel ms, out[3] = shader clock (Hz).  The roof the gapped half of `blastn` (reference
- * README.md:96) is measured against: that stage is instruction-bound, not memory-bound */
+ * README.md:96) is measured against next to the random-line roof (pgx_probe_gather): DESIGN.md section 7 found that stage
+ * bound by single-use 64-byte lines first and by instruction issue second */
 int pgx_probe_issue(int waves_per_simd, int kind, double *out);
 const char *pgx_probe_issue_name(int kind); /* NULL past the last kind */
 

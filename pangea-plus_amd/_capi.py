@@ -85,7 +85,7 @@ VOTE_DTYPE = np.dtype([("depth", "<i4"), ("name", "<u4", (7,)), ("votes", "u1", 
 
 # every symbol include/pangea_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_db_build", "pgx_db_open",
+    "pgx_last_error", "pgx_version", "pgx_init", "pgx_device_count", "pgx_current_device", "pgx_db_build", "pgx_db_open",
     "pgx_db_from_fasta", "pgx_db_close", "pgx_db_num_seqs", "pgx_db_num_bases", "pgx_db_seq_id",
     "pgx_db_device_arrays", "pgx_db_get_shape", "pgx_db_alloc_like", "pgx_db_finish_import", "pgx_db_checksum", "pgx_blastn_run", "pgx_db_set_ungapped", "pgx_db_set_dust", "pgx_db_set_dust_each_search",
     "pgx_soap_index", "pgx_soap_run", "pgx_tax_create", "pgx_tax_open", "pgx_tax_close", "pgx_tax_gi2taxid",

@@ -32,20 +32,35 @@ int fail(int status, const char *fmt, ...)
 	return status;
 }
 
+// The device of this process: what pgx_init() chose, else PGX_DEVICE, else device 0.  hipSetDevice() is a per-thread
+// setting, so every host thread that enters the library is bound to the process's device on its first call (a thread of
+// a process that chose device 3 used to land on device 0).
+static thread_local int t_device = -1;
+
 int require_device()
 {
-	if (g_device >= 0)
+	if (g_device >= 0 && t_device == g_device)
 		return 0;
-	int n = 0;
-	hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n <= 0)
-		return fail(PGX_E_NODEVICE,
-			    "no HIP device: libpangea_hip has no CPU path (hipGetDeviceCount: %s, %d devices)",
-			    hipGetErrorString(e), n);
-	e = hipSetDevice(0);
+	int want = g_device;
+	if (want < 0) {
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0)
+			return fail(PGX_E_NODEVICE,
+				    "no HIP device: libpangea_hip has no CPU path (hipGetDeviceCount: %s, %d devices)",
+				    hipGetErrorString(e), n);
+		want = 0;
+		if (const char *env = getenv("PGX_DEVICE")) {
+			want = atoi(env);
+			if (want < 0 || want >= n)
+				return fail(PGX_E_ARG, "PGX_DEVICE=%s is outside 0..%d", env, n - 1);
+		}
+	}
+	const hipError_t e = hipSetDevice(want);
 	if (e != hipSuccess)
-		return fail(PGX_E_NODEVICE, "hipSetDevice(0) failed: %s", hipGetErrorString(e));
-	g_device = 0;
+		return fail(PGX_E_NODEVICE, "hipSetDevice(%d) failed: %s", want, hipGetErrorString(e));
+	g_device = want;
+	t_device = want;
 	return 0;
 }
 
@@ -196,8 +211,11 @@ int pgx_init(int device)
 	if (e != hipSuccess)
 		return pgx::fail(PGX_E_NODEVICE, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
 	pgx::g_device = device;
+	pgx::t_device = device;
 	return 0;
 }
+
+int pgx_current_device(void) { return pgx::g_device; }
 
 void pgx_free(void *p) { free(p); }
 }

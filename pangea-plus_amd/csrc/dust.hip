@@ -460,17 +460,33 @@ __global__ __launch_bounds__(256) void k_dust_order_scatter(const uint32_t *__re
 }
 
 // list / range (n entries, count on the device) -> list_s / range_s in the order above
-static int dust_order(pgx_reads *rd, const uint32_t *list, const uint2 *range, const uint32_t *n_ptr, size_t n_max, hipStream_t stream)
+static int dust_order(DustBufs &b, const uint32_t *list, const uint2 *range, const uint32_t *n_ptr, size_t n_max, hipStream_t stream)
 {
 	if (n_max == 0)
 		return 0;
-	PGX_HIP(hipMemsetAsync(rd->d_dust_hist.data(), 0, 512 * sizeof(uint32_t), stream));
+	PGX_HIP(hipMemsetAsync(b.hist.data(), 0, 512 * sizeof(uint32_t), stream));
 	const unsigned grid = (unsigned)std::min<size_t>((n_max + 2047) / 2048, 256 * 8);
-	hipLaunchKernelGGL(k_dust_order_hist, dim3(grid), dim3(256), 0, stream, range, n_ptr, rd->d_dust_hist.data());
-	hipLaunchKernelGGL(k_dust_order_bases, dim3(1), dim3(64), 0, stream, rd->d_dust_hist.data());
-	hipLaunchKernelGGL(k_dust_order_scatter, dim3(grid), dim3(256), 0, stream, list, range, n_ptr, rd->d_dust_hist.data(), rd->d_dust_list_s.data(),
-			   rd->d_dust_range_s.data());
+	hipLaunchKernelGGL(k_dust_order_hist, dim3(grid), dim3(256), 0, stream, range, n_ptr, b.hist.data());
+	hipLaunchKernelGGL(k_dust_order_bases, dim3(1), dim3(64), 0, stream, b.hist.data());
+	hipLaunchKernelGGL(k_dust_order_scatter, dim3(grid), dim3(256), 0, stream, list, range, n_ptr, b.hist.data(), b.list_s.data(),
+			   b.range_s.data());
 	PGX_HIP(hipGetLastError());
+	return 0;
+}
+
+// buffers of a pass over a batch of n reads, n_mask window words; `listed` = what the second list needs (0: not known yet)
+static int dust_bufs_ensure(DustBufs &b, size_t n, size_t n_mask, size_t listed)
+{
+	PGX_TRY(b.mask.ensure(n_mask));
+	PGX_TRY(b.any.ensure(n));
+	PGX_TRY(b.list.ensure(n));
+	PGX_TRY(b.range.ensure(n));
+	PGX_TRY(b.list_s.ensure(n));
+	PGX_TRY(b.range_s.ensure(n));
+	PGX_TRY(b.hist.ensure(512));
+	PGX_TRY(b.n.ensure(2));
+	if (listed)
+		PGX_TRY(b.list2.ensure(listed));
 	return 0;
 }
 
@@ -481,47 +497,37 @@ int reads_dust(pgx_reads *rd)
 	rd->has_dust = false;
 	if (n == 0)
 		return 0;
-	DevBuf<uint64_t> &d_mask = rd->d_dust_mask;
-	DevBuf<uint8_t> &d_any = rd->d_dust_any;
-	DevBuf<uint32_t> &d_list = rd->d_dust_list, &d_list2 = rd->d_dust_list2, &d_nlist = rd->d_dust_n;
-	DevBuf<uint2> &d_range = rd->d_dust_range;
+	DustBufs &b = rd->dustb;
 	const size_t n_mask = (size_t)rd->n_words + 24;
-	PGX_TRY(d_mask.ensure(n_mask));
-	PGX_HIP(hipMemsetAsync(d_mask.data(), 0, n_mask * sizeof(uint64_t), 0));
-	PGX_TRY(d_any.ensure(n));
-	PGX_HIP(hipMemsetAsync(d_any.data(), 0, n, 0));
-	PGX_TRY(d_list.ensure(n));
-	PGX_TRY(d_range.ensure(n));
-	PGX_TRY(rd->d_dust_list_s.ensure(n));
-	PGX_TRY(rd->d_dust_range_s.ensure(n));
-	PGX_TRY(rd->d_dust_hist.ensure(512));
-	PGX_TRY(d_nlist.ensure(2));
-	PGX_HIP(hipMemsetAsync(d_nlist.data(), 0, 2 * sizeof(uint32_t), 0));
+	PGX_TRY(dust_bufs_ensure(b, n, n_mask, 0));
+	PGX_HIP(hipMemsetAsync(b.mask.data(), 0, n_mask * sizeof(uint64_t), 0));
+	PGX_HIP(hipMemsetAsync(b.any.data(), 0, n, 0));
+	PGX_HIP(hipMemsetAsync(b.n.data(), 0, 2 * sizeof(uint32_t), 0));
 	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
 	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, d_list.data(), d_range.data(),
-			   d_nlist.data());
+			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b.list.data(), b.range.data(),
+			   b.n.data());
 	PGX_HIP(hipGetLastError());
 	uint32_t n_listed[2] = { 0, 0 };
-	PGX_TRY(d_nlist.download(n_listed, 1));
+	PGX_TRY(b.n.download(n_listed, 1));
 	if (n_listed[0]) {
-		PGX_TRY(d_list2.ensure(n_listed[0]));
-		PGX_TRY(dust_order(rd, d_list.data(), d_range.data(), d_nlist.data(), n_listed[0], 0));
+		PGX_TRY(b.list2.ensure(n_listed[0]));
+		PGX_TRY(dust_order(b, b.list.data(), b.range.data(), b.n.data(), n_listed[0], 0));
 		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((n_listed[0] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list_s.data(), d_nlist.data(), d_list2.data(), d_range.data(),
-				   d_nlist.data() + 1);
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.list_s.data(), b.n.data(), b.list2.data(), b.range.data(),
+				   b.n.data() + 1);
 		PGX_HIP(hipGetLastError());
-		PGX_TRY(d_nlist.download(n_listed, 2));
+		PGX_TRY(b.n.download(n_listed, 2));
 	}
 	if (n_listed[1]) {
-		PGX_TRY(dust_order(rd, d_list2.data(), d_range.data(), d_nlist.data() + 1, n_listed[1], 0));
+		PGX_TRY(dust_order(b, b.list2.data(), b.range.data(), b.n.data() + 1, n_listed[1], 0));
 		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed[1] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), rd->d_dust_list_s.data(), rd->d_dust_range_s.data(), d_nlist.data() + 1, d_mask.data(), d_any.data());
+				   rd->d_woff.data(), b.list_s.data(), b.range_s.data(), b.n.data() + 1, b.mask.data(), b.any.data());
 		PGX_HIP(hipGetLastError());
 	}
 	std::vector<uint8_t> &h_any = rd->h_read_dust;
 	h_any.resize(n);
-	PGX_TRY(d_any.download(h_any.data(), n));
+	PGX_TRY(b.any.download(h_any.data(), n));
 	bool some = false;
 	for (size_t i = 0; i < n && !some; i++)
 		some = h_any[i] != 0;
@@ -529,12 +535,12 @@ int reads_dust(pgx_reads *rd)
 		h_any.clear();
 		return 0; // no read of the batch has a masked base: the seed stage runs as without DUST
 	}
-	PGX_TRY(rd->d_dustwin_f.ensure(n_mask));
-	PGX_TRY(rd->d_dustwin_r.ensure(n_mask));
-	PGX_HIP(hipMemsetAsync(rd->d_dustwin_f.data(), 0, n_mask * sizeof(uint64_t), 0));
-	PGX_HIP(hipMemsetAsync(rd->d_dustwin_r.data(), 0, n_mask * sizeof(uint64_t), 0));
-	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, d_mask.data(), d_any.data(), rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, rd->d_dustwin_f.data(), rd->d_dustwin_r.data());
+	PGX_TRY(b.win_f.ensure(n_mask));
+	PGX_TRY(b.win_r.ensure(n_mask));
+	PGX_HIP(hipMemsetAsync(b.win_f.data(), 0, n_mask * sizeof(uint64_t), 0));
+	PGX_HIP(hipMemsetAsync(b.win_r.data(), 0, n_mask * sizeof(uint64_t), 0));
+	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, b.mask.data(), b.any.data(), rd->d_len.data(),
+			   rd->d_woff.data(), (uint32_t)n, b.win_f.data(), b.win_r.data());
 	PGX_HIP(hipGetLastError());
 	PGX_HIP(hipDeviceSynchronize());
 	rd->has_dust = true;
@@ -543,39 +549,45 @@ int reads_dust(pgx_reads *rd)
 	return 0;
 }
 
-// The same passes again on a resident batch, on `stream`, without a host wait: S3d as part of a search (BLAST masks its
-// queries inside every search; `pgx_db_set_dust_each_search`).  The masks depend on the reads alone, so the launch sizes the
-// first pass found (and the search classes made from its per-read flags) hold; the kernels take their counts on the device.
-int reads_dust_again(pgx_reads *rd, hipStream_t stream)
+// The same passes again over a resident batch, on `stream`, without a host wait, INTO THE CALLER'S BUFFERS: S3d as part of a
+// search (BLAST masks its queries inside every search; `pgx_db_set_dust_each_search`).  The batch is only read: the buffers
+// belong to the searching handle's workspace, so searches of one batch through two handles do not meet.  The
+// masks depend on the reads alone, so the launch sizes the import's pass found (and the search classes made from its
+// per-read flags) hold; the kernels take their counts on the device.
+int reads_dust_again(const pgx_reads *rd, DustBufs &b, hipStream_t stream)
 {
 	const size_t n = (size_t)rd->n;
-	if (n == 0 || !rd->d_dust_mask.base)
+	if (n == 0 || !rd->dustb.mask.base)
 		return 0;
 	const size_t n_mask = (size_t)rd->n_words + 24;
-	PGX_HIP(hipMemsetAsync(rd->d_dust_mask.data(), 0, n_mask * sizeof(uint64_t), stream));
-	PGX_HIP(hipMemsetAsync(rd->d_dust_any.data(), 0, n, stream));
-	PGX_HIP(hipMemsetAsync(rd->d_dust_n.data(), 0, 2 * sizeof(uint32_t), stream));
+	PGX_TRY(dust_bufs_ensure(b, n, n_mask, rd->dust_listed[0]));
+	if (rd->has_dust) {
+		PGX_TRY(b.win_f.ensure(n_mask));
+		PGX_TRY(b.win_r.ensure(n_mask));
+	}
+	PGX_HIP(hipMemsetAsync(b.mask.data(), 0, n_mask * sizeof(uint64_t), stream));
+	PGX_HIP(hipMemsetAsync(b.any.data(), 0, n, stream));
+	PGX_HIP(hipMemsetAsync(b.n.data(), 0, 2 * sizeof(uint32_t), stream));
 	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
 	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, rd->d_dust_list.data(),
-			   rd->d_dust_range.data(), rd->d_dust_n.data());
+			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b.list.data(),
+			   b.range.data(), b.n.data());
 	if (rd->dust_listed[0]) {
-		PGX_TRY(dust_order(rd, rd->d_dust_list.data(), rd->d_dust_range.data(), rd->d_dust_n.data(), rd->dust_listed[0], stream));
+		PGX_TRY(dust_order(b, b.list.data(), b.range.data(), b.n.data(), rd->dust_listed[0], stream));
 		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((rd->dust_listed[0] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dust_list_s.data(), rd->d_dust_n.data(), rd->d_dust_list2.data(),
-				   rd->d_dust_range.data(), rd->d_dust_n.data() + 1);
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.list_s.data(), b.n.data(), b.list2.data(),
+				   b.range.data(), b.n.data() + 1);
 	}
 	if (rd->dust_listed[1]) {
-		PGX_TRY(dust_order(rd, rd->d_dust_list2.data(), rd->d_dust_range.data(), rd->d_dust_n.data() + 1, rd->dust_listed[1], stream));
+		PGX_TRY(dust_order(b, b.list2.data(), b.range.data(), b.n.data() + 1, rd->dust_listed[1], stream));
 		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((rd->dust_listed[1] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), rd->d_dust_list_s.data(), rd->d_dust_range_s.data(), rd->d_dust_n.data() + 1, rd->d_dust_mask.data(),
-				   rd->d_dust_any.data());
+				   rd->d_woff.data(), b.list_s.data(), b.range_s.data(), b.n.data() + 1, b.mask.data(), b.any.data());
 	}
 	if (rd->has_dust) {
-		PGX_HIP(hipMemsetAsync(rd->d_dustwin_f.data(), 0, n_mask * sizeof(uint64_t), stream));
-		PGX_HIP(hipMemsetAsync(rd->d_dustwin_r.data(), 0, n_mask * sizeof(uint64_t), stream));
-		hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, rd->d_dust_mask.data(), rd->d_dust_any.data(),
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, rd->d_dustwin_f.data(), rd->d_dustwin_r.data());
+		PGX_HIP(hipMemsetAsync(b.win_f.data(), 0, n_mask * sizeof(uint64_t), stream));
+		PGX_HIP(hipMemsetAsync(b.win_r.data(), 0, n_mask * sizeof(uint64_t), stream));
+		hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, b.mask.data(), b.any.data(),
+				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.win_f.data(), b.win_r.data());
 	}
 	PGX_HIP(hipGetLastError());
 	return 0;

@@ -73,6 +73,21 @@ struct pgx_db {
 };
 
 // A batch of reads in HBM: forward and reverse-complement strands, each read word-aligned.
+namespace pgx {
+// Everything a DUST pass over a batch writes (dust.hip).  A batch owns one set (made at import); a database handle owns
+// another for searches that compute S3d again (pgx_db_set_dust_each_search): a search never writes into the batch it is
+// given, so two handles may search one batch from two threads.
+struct DustBufs {
+	DevBuf<uint64_t> win_f, win_r; // per strand one bit per read position: the 28 bases from there touch no masked base
+	DevBuf<uint8_t> any;            // per read: it has a masked base (the others skip the window bits)
+	DevBuf<uint64_t> mask;
+	DevBuf<uint32_t> list, list2, n;
+	DevBuf<uint2> range;
+	DevBuf<uint32_t> list_s, hist; // a list ordered by the length of its entries' ranges; the 256 + 256 counters of that sort
+	DevBuf<uint2> range_s;
+};
+} // namespace pgx
+
 struct pgx_reads {
 	int64_t n = 0;
 	int64_t first = 0; // ordinal of read 0 within its source (names r<first+i> for synthetic reads)
@@ -104,14 +119,7 @@ struct pgx_reads {
 	// masks; 64 positions per word at the read's word offset; absent when no read of the batch has a masked base
 	bool has_dust = false;
 	uint32_t dust_listed[2] = { 0, 0 }; // reads the first / second trigger pass listed when the batch was made
-	pgx::DevBuf<uint64_t> d_dustwin_f, d_dustwin_r;
-	pgx::DevBuf<uint8_t> d_dust_any; // per read: it has a masked base (the others skip the window bits)
-	// scratch of the DUST pass, kept with the batch so that a repeated pass (pgx_reads_redo_dust) allocates nothing
-	pgx::DevBuf<uint64_t> d_dust_mask;
-	pgx::DevBuf<uint32_t> d_dust_list, d_dust_list2, d_dust_n;
-	pgx::DevBuf<uint2> d_dust_range;
-	pgx::DevBuf<uint32_t> d_dust_list_s, d_dust_hist; // a list ordered by the length of its entries' ranges; the 256 + 256 counters of that sort
-	pgx::DevBuf<uint2> d_dust_range_s;
+	pgx::DustBufs dustb; // what the batch's own DUST pass (at import; pgx_reads_redo_dust) wrote
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
 	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the
 	// stretches between such runs (seqdb.hip: reads_build_pieces): `pieces` is a batch of its own, pieces of a read
@@ -279,7 +287,7 @@ int choose_index_bits(int64_t n_postings);
 
 // dust.hip
 int reads_dust(pgx_reads *rd);
-int reads_dust_again(pgx_reads *rd, hipStream_t stream);
+int reads_dust_again(const pgx_reads *rd, DustBufs &b, hipStream_t stream);
 
 // classify.hip
 struct SearchCounters {

@@ -67,3 +67,59 @@ def test_dry_ranks_reports_every_rank_and_compares_the_database_copies():
     assert (r0["rank"], r1["rank"]) == (0, 1) and r0["checksum"] == r1["checksum"] and all(x > 0 for x in r0["checksum"])
     assert r1["index_rebuild_s"] > 0 and r0["hbm_free_GiB"] > 1
     assert verdict == {"dry_ranks": 2, "ranks_that_differ_from_rank_0": 0, "ranks": []}
+
+
+@pytest.fixture(scope="module")
+def mpi_workload(tmp_path_factory, oracle_bin):
+    """3 001 reads (divisible by neither 2 nor 8) against a 1.2 Mbp database; the checker's table is the expected file."""
+    from conftest import run_cmd
+    d = tmp_path_factory.mktemp("mpi")
+    args = ["--n-seq", "2000", "--seq-len", "600", "--n-genus", "50", "--read-len", "150"]
+    assert run_cmd([oracle_bin, "synth", "db", "--out", str(d / "db.fa")] + args)[0] == 0
+    assert run_cmd([oracle_bin, "synth", "reads", "--out", str(d / "reads.fa"), "--count", "3001"] + args)[0] == 0
+    rc, _, se = run_cmd([oracle_bin, "blastn", "-query", str(d / "reads.fa"), "-db", str(d / "db.fa"), "-outfmt", "6", "-out",
+                         str(d / "oracle.tsv"), "-num_threads", "8"], timeout=600)
+    assert rc == 0, se
+    bin_dir = os.path.join(ROOT, "pangea-plus_amd", "bin")
+    p = subprocess.run([os.path.join(bin_dir, "makeblastdb"), "-in", str(d / "db.fa"), "-out", str(d / "nt"), "-dbtype", "nucl"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return d
+
+
+@pytest.mark.parametrize("n_proc", [1, 2, 8])
+def test_mpiblastn_file_verb_with_n_processes_equals_the_one_process_table(mpi_workload, tmp_path, n_proc):
+    """`mpiblastn in.fasta db out N` (reference Scripts/submit_MPI-blast.job:24, submit_multiple_MPI-blast.job:24): the
+    launcher starts N rank processes (device = rank mod devices: all on GPU 0 of this box, at most four at a time),
+    each searches its block of the query file, the concatenation in rank order is byte for byte the checker's table."""
+    exe = os.path.join(ROOT, "pangea-plus_amd", "bin", "mpiblastn")
+    out = tmp_path / "hits.txt"
+    p = subprocess.run([exe, str(mpi_workload / "reads.fa"), str(mpi_workload / "nt"), str(out), str(n_proc)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=_env())
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    want = open(mpi_workload / "oracle.tsv", "rb").read()
+    assert len(want) > 100000 and out.read_bytes() == want
+    assert not [f for f in os.listdir(tmp_path) if ".rank" in f]  # the rank files are gone
+
+
+def test_mpiblastn_relays_the_worst_rank_status_and_blastn_takes_a_device(mpi_workload, tmp_path):
+    exe = os.path.join(ROOT, "pangea-plus_amd", "bin", "mpiblastn")
+    out = tmp_path / "hits.txt"
+    p = subprocess.run([exe, str(mpi_workload / "reads.fa"), str(tmp_path / "no_such_db"), str(out), "3"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_env())
+    assert p.returncode == 2 and b"rank" in p.stderr
+    # `blastn -rank r -world_size N -gpu g`: the rank no longer implies device 0; a device that does not exist is an error
+    blastn = os.path.join(ROOT, "pangea-plus_amd", "bin", "blastn")
+    base = [blastn, "-query", str(mpi_workload / "reads.fa"), "-db", str(mpi_workload / "nt"), "-outfmt", "6"]
+    parts = b""
+    for rk in range(3):
+        o = tmp_path / ("b%d.tsv" % rk)
+        extra = ["-gpu", "0"] if rk == 1 else []      # rank 2 without -gpu: 2 mod (1 device) = 0
+        p = subprocess.run(base + ["-out", str(o), "-rank", str(rk), "-world_size", "3"] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300, env=_env())
+        assert p.returncode == 0, p.stderr
+        parts += o.read_bytes()
+    assert parts == open(mpi_workload / "oracle.tsv", "rb").read()
+    p = subprocess.run(base + ["-out", str(tmp_path / "x.tsv"), "-gpu", "99"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=_env())
+    assert p.returncode == 2 and b"device 99" in p.stderr

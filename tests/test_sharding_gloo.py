@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two gloo ranks run the same sharding/broadcast code bench.py runs over RCCL."""
+"""The N > 1 path on CPU: 2, 4 and 8 gloo ranks run the same sharding/broadcast code bench.py runs over RCCL."""
 import os
 import sys
 
@@ -62,9 +62,10 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
-    world = 2
-    port = 29600 + os.getpid() % 300
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gloo_broadcast_and_sharding(tmp_path, world):
+    """World sizes 2, 4 and 8 (config 4 is 8 ranks): 1 003 reads do not divide by any of them."""
+    port = 29600 + os.getpid() % 300 + world
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / ("rank%d.ok" % r)).read_text() == "1"
@@ -104,3 +105,26 @@ def test_bench_parent_starts_the_ranks_as_a_child_process(tmp_path):
     argv = (tmp_path / "argv.txt").read_text().split()
     assert argv[:2] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in argv
     assert argv[argv.index("--nproc-per-node") + 1] == "2" and argv[-4:] == ["--gpus", "2", "--steps", "3"]
+
+
+def test_mpiblastn_without_a_gpu_fails_loudly_and_leaves_the_output_alone(tmp_path):
+    """`mpiblastn in.fasta db out N` (reference Scripts/submit_MPI-blast.job:24): the launcher asks a child process for
+    the device count; with no GPU it says so, exits non-zero and does not create (or truncate) the output file."""
+    import subprocess
+    exe = os.path.join(ROOT, "pangea-plus_amd", "bin", "mpiblastn")
+    if not os.path.exists(exe):
+        pytest.skip("CLIs not built")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    q = tmp_path / "q.fa"
+    q.write_text(">a\nACGT\n")
+    out = tmp_path / "out.txt"
+    out.write_text("keep me\n")
+    p = subprocess.run([exe, str(q), str(tmp_path / "db"), str(out), "8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 2 and b"no HIP device" in p.stderr
+    assert out.read_text() == "keep me\n"
+    p = subprocess.run([exe, str(q), str(tmp_path / "db"), str(out), "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 1 and b"USAGE" in p.stderr
+    p = subprocess.run([exe, str(tmp_path / "nope.fa"), str(tmp_path / "db"), str(out), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 2 and b"cannot open query file" in p.stderr
