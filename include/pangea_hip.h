@@ -247,6 +247,11 @@ int64_t pgx_hits_count(const pgx_hits *h); /* slots */
 int pgx_hits_copy(const pgx_hits *h, pgx_hit *out, int64_t cap);           /* device -> host */
 int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap);   /* n_reads+1 slot offsets */
 int pgx_hits_read_counts(const pgx_hits *h, int64_t *out, int64_t cap);    /* n_reads row counts */
+/* The rows of reads [first_read, first_read + n_reads) as a table of its own (read numbers and offsets from 0): what a
+ * caller formats, downloads or hands to the next tool piece by piece when the whole table of a batch (9 GB for 10 M reads)
+ * is too much at once -- the table of one `blastn` process is one file in the reference (README.md:96), a piece of it here.
+ * Consensus records of the window are the batch's with `hit` minus the first offset of the window. */
+int pgx_hits_slice(const pgx_hits *h, int64_t first_read, int64_t n_reads, pgx_hits **out);
 /* -outfmt 6 text of the table, malloc'd (pgx_free) */
 int pgx_hits_format(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads, char **text, size_t *len);
 
@@ -377,6 +382,7 @@ typedef struct {
 	float gapped_ms;     /* spec v2: the gapped stage between seed_extend and group */
 	int64_t gapped_wide; /* HSPs the first tier of the gapped stage listed for the later ones */
 	float dust_ms;       /* S3d recomputed inside the search (pgx_db_set_dust_each_search), else 0; part of total_ms */
+	int32_t attempts;    /* 1, or more when a table or list of the step was too small and the step was repeated with larger ones */
 } pgx_stage_times;
 int pgx_last_stage_times(pgx_stage_times *out);
 

@@ -55,7 +55,7 @@ class StageTimes(C.Structure):
     _fields_ = [("seed_extend_ms", C.c_float), ("group_ms", C.c_float), ("sort_ms", C.c_float),
                 ("consensus_ms", C.c_float), ("total_ms", C.c_float), ("probes", C.c_int64), ("postings", C.c_int64),
                 ("candidates", C.c_int64), ("hits", C.c_int64), ("survivors", C.c_int64), ("gapped_ms", C.c_float),
-                ("gapped_wide", C.c_int64), ("dust_ms", C.c_float)]
+                ("gapped_wide", C.c_int64), ("dust_ms", C.c_float), ("attempts", C.c_int32)]
 
 
 class _DevArray(C.Structure):
@@ -93,7 +93,7 @@ SYMBOLS = [
     "pgx_tax_lineage_batch", "pgx_taxcollect_file", "pgx_consensus_file", "pgx_synth_default", "pgx_db_from_synth",
     "pgx_synth_write_taxdump", "pgx_reads_from_fasta", "pgx_reads_from_fasta_text", "pgx_reads_from_synth", "pgx_reads_write_fasta", "pgx_reads_redo_dust", "pgx_rdp_write_file", "pgx_reads_close", "pgx_reads_count",
     "pgx_reads_get", "pgx_blast_search", "pgx_hits_close", "pgx_hits_count", "pgx_hits_copy",
-    "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
+    "pgx_hits_read_offsets", "pgx_hits_read_counts", "pgx_hits_slice", "pgx_hits_format", "pgx_db_bind_taxonomy", "pgx_db_subject_lineage",
     "pgx_rdp_from_file", "pgx_rdp_from_synth", "pgx_rdp_close", "pgx_consensus_batch", "pgx_classify_consensus", "pgx_classify_consensus_tri", "pgx_vote3_batch", "pgx_vote3_format",
     "pgx_consensus_format", "pgx_consensus_format_file", "pgx_last_stage_times", "pgx_megaclust_file", "pgx_megaclust_batch", "pgx_megaclustable", "pgx_trim_file", "pgx_blast_score_columns", "pgx_blast_score_columns_v", "pgx_probe_gather", "pgx_probe_issue", "pgx_probe_issue_name",
 ]
@@ -367,6 +367,12 @@ class Hits(_Handle):
         txt, ln = C.c_void_p(), C.c_size_t()
         _check(lib().pgx_hits_format(self.ptr, db.ptr, reads.ptr, C.byref(txt), C.byref(ln)))
         return _take_text(txt.value, ln.value)
+
+    def slice(self, first_read, n_reads):
+        """The rows of reads [first_read, +n_reads) as a table of its own (read numbers and offsets from 0)."""
+        p = C.c_void_p()
+        _check(lib().pgx_hits_slice(self.ptr, C.c_int64(first_read), C.c_int64(n_reads), C.byref(p)))
+        return Hits(p)
 
 
 class Rdp(_Handle):

@@ -1739,6 +1739,26 @@ __global__ void k_consensus_serial(const pgx_hit *__restrict__ hits, const uint3
 }
 
 // ------------------------------------------------------------------------------------------ host drivers
+// a window of a hit table as a table of its own (pgx_hits_slice): offsets from 0, read numbers from 0
+__global__ void k_slice_offsets(const uint32_t *__restrict__ off, const uint32_t *__restrict__ cnt, uint32_t first, uint32_t n,
+				 uint32_t *__restrict__ off_out, uint32_t *__restrict__ cnt_out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n)
+		off_out[i] = off[first + i] - off[first];
+	if (i < n)
+		cnt_out[i] = cnt[first + i];
+}
+
+__global__ void k_slice_hits(const pgx_hit *__restrict__ in, uint64_t base, uint64_t n_slots, uint32_t first, pgx_hit *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+		pgx_hit h = in[base + i];
+		h.read -= (int32_t)first;
+		out[i] = h;
+	}
+}
+
 static thread_local pgx_stage_times t_times; // stage times of the calling thread's last pipeline call
 
 static DbView db_view(const pgx_db *db)
@@ -2149,6 +2169,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			table_cap = H + H / 16;
 			again = true;
 		}
+		tm.attempts = attempt + 1;
 		if (!again)
 			break;
 	}
@@ -2313,6 +2334,36 @@ int pgx_hits_copy(const pgx_hits *h, pgx_hit *out, int64_t cap)
 	if (!h || !out || cap < h->n_hits)
 		return fail(PGX_E_ARG, "pgx_hits_copy: bad argument");
 	return h->d_hits.download(out, (size_t)h->n_hits);
+}
+
+int pgx_hits_slice(const pgx_hits *h, int64_t first_read, int64_t n_reads, pgx_hits **out)
+{
+	if (!h || !out || first_read < 0 || n_reads < 0 || first_read + n_reads > h->n_reads)
+		return fail(PGX_E_ARG, "pgx_hits_slice: reads [%lld, +%lld) are not inside a table of %lld reads", (long long)first_read,
+			    (long long)n_reads, (long long)(h ? h->n_reads : 0));
+	PGX_TRY(require_device());
+	return guard("pgx_hits_slice", [&]() -> int {
+		std::unique_ptr<pgx_hits> s(new pgx_hits);
+		s->n_reads = n_reads;
+		s->gapped = h->gapped;
+		PGX_TRY(s->d_read_off.alloc((size_t)n_reads + 1));
+		PGX_TRY(s->d_read_cnt.alloc((size_t)n_reads + 1));
+		uint32_t ends[2] = { 0, 0 };
+		PGX_TRY(h->d_read_off.download(&ends[0], 1, (size_t)first_read));
+		PGX_TRY(h->d_read_off.download(&ends[1], 1, (size_t)(first_read + n_reads)));
+		const uint64_t n_slots = (uint64_t)ends[1] - ends[0];
+		s->n_hits = (int64_t)n_slots;
+		PGX_TRY(s->d_hits.alloc(n_slots ? n_slots : 1));
+		hipLaunchKernelGGL(k_slice_offsets, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, 0, h->d_read_off.data(), h->d_read_cnt.data(),
+				   (uint32_t)first_read, (uint32_t)n_reads, s->d_read_off.data(), s->d_read_cnt.data());
+		if (n_slots)
+			hipLaunchKernelGGL(k_slice_hits, dim3((unsigned)std::min<uint64_t>((n_slots + 255) / 256, 256ull * 32)), dim3(256), 0, 0, h->d_hits.data(),
+					   (uint64_t)ends[0], n_slots, (uint32_t)first_read, s->d_hits.data());
+		PGX_HIP(hipGetLastError());
+		PGX_HIP(hipDeviceSynchronize());
+		*out = s.release();
+		return 0;
+	});
 }
 
 int pgx_hits_read_offsets(const pgx_hits *h, int64_t *out, int64_t cap)

@@ -62,49 +62,76 @@ __device__ __forceinline__ void dust_wave_sync()
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
-
-// (the first pass never walks the longer suffixes: without `ct` its wavefront needs 8.4 KB of LDS instead of 12.5 -- 4 to a
-// SIMD instead of 3 for a kernel that waits on its own LDS counters)
-template <bool CONFIRM> struct TrigLaneT {
-	uint8_t cw[64], cv[64], ct[CONFIRM ? 64 : 4];
-	uint32_t pad[CONFIRM ? 1 : 2]; // an odd word stride per lane: an even one put the 64 lanes' counters on two LDS banks (32-way conflicts)
-};
-static_assert(sizeof(TrigLaneT<true>) / 4 % 2 == 1 && sizeof(TrigLaneT<false>) / 4 % 2 == 1, "odd word stride");
-
-// the trigger works on raw 6-bit triplet codes (any one-to-one naming of the 64 triplets counts the same pairs)
-__device__ __forceinline__ int dust_tid(const uint64_t *rw, const uint64_t *ra, int i)
+// the same for operations that only have to STAY in program order (the LDS unit takes a wavefront's operations in the order
+// they were issued): nothing to wait for, the compiler just may not move memory operations across
+__device__ __forceinline__ void dust_wave_order()
 {
-	if (ra && (window64(ra, i) & 0x15ull))
-		return -1;
-	return (int)(window64(rw, i) & 63ull);
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
 }
 
-// CONFIRM = false: every read of the batch, the algorithm's own test only (a read that never passes it is done);
-// CONFIRM = true: the reads the first pass listed, packed 64 to a wavefront, with the walk over the longer suffixes at every
-// position that passes (kept out of the first pass: one lane walking there held up the other 63)
-template <bool CONFIRM>
-__global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
-						      const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
-						      const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ n_in,
-						      uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
+// an odd word stride per lane: an even one put the 64 lanes' counters on two LDS banks (32-way conflicts)
+struct TrigLane {
+	uint8_t cw[64], cv[64];
+	uint32_t pad;
+};
+static_assert(sizeof(TrigLane) / 4 % 2 == 1, "odd word stride");
+
+// 64 bits of a read held in registers (R[k] = its k-th word, R[NW] .. = 0), from base `pos`; `pos` is the same in every lane
+template <int NR> __device__ __forceinline__ uint64_t reg_window64(const uint64_t (&R)[NR], int pos)
 {
-	using TrigLane = TrigLaneT<CONFIRM>;
+	const int wi = __builtin_amdgcn_readfirstlane(pos >> 5), sh = (pos & 31) * 2;
+	uint64_t lo = 0, hi = 0;
+#pragma unroll
+	for (int k = 0; k + 1 < NR; k++)
+		if (wi == k) {
+			lo = R[k];
+			hi = R[k + 1];
+		}
+	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane_uniform)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+// First pass, every read of the batch, one lane per read: the published algorithm's own bookkeeping and its test
+// "10 r_w > 20 L" (header).  Lists the reads with a position that passes, with the first and last such position.
+// NW > 0: reads of at most 32 NW bases without ambiguity letters, the whole read in NW 64-bit registers per lane -- no
+// memory access inside the loop.  Round 3's form (NW = 0: any length, ambiguity flags) fetched the letters of a suffix it
+// shrinks from memory, one dependent trip per shrink, and some lane shrinks at most positions: the kernel ran at the
+// latency of that load (4.0 ms per 10 M reads of 150 bases).
+template <int NW>
+__global__ __launch_bounds__(64) void k_dust_scan(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
+						   const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
+						   uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
+{
+	constexpr bool REGS = NW > 0;
+	constexpr int NR = REGS ? NW + 4 : 1;
 	__shared__ TrigLane s_lane[64];
-	__shared__ uint32_t s_hist[64];
 	TrigLane &ld = s_lane[threadIdx.x];
 	const uint32_t at0 = blockIdx.x * 64u + threadIdx.x;
 	// (every lane runs the loop: the wavefront shrinks suffixes together; a lane past the end has no read)
-	const bool has_read = at0 < (CONFIRM ? *n_in : n);
-	const uint32_t r = has_read ? (CONFIRM ? in_list[at0] : at0) : 0u;
+	const bool has_read = at0 < n;
+	const uint32_t r = has_read ? at0 : 0u;
 	const int nt = (int)len[r] - 2;
-	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
+	const uint64_t *rw = fwd + woff[r], *ra = (!REGS && amb) ? amb + woff[r] : nullptr;
+	uint64_t R[NR];
+	if constexpr (REGS) {
+#pragma unroll
+		for (int k = 0; k < NR; k++)
+			R[k] = k < NW ? rw[k] : 0ull; // (the packed reads carry spare words behind every read)
+	}
 	uint32_t *c32 = reinterpret_cast<uint32_t *>(&ld);
 	for (int k = 0; k < 32; k++)
 		c32[k] = 0u;
 	int first = -1, last = -1;
-	int size = 0, L = 0, rw_pairs = 0, rv_pairs = 0; // the window is the `size` triplets that end at the current one
+	int size = 0, L = 0, rw_pairs = 0; // the window is the `size` triplets that end at the current one
 	// the entering and the leaving triplet come from two 64-bit registers that hold the next 32 letters each and move on
-	// by one letter per position (refilled every 16 positions); only the rare steps below go back to memory
+	// by one letter per position (refilled every 16 positions)
 	uint64_t in_w = 0, out_w = 0;
 	int out_pos = -1;
 	int nt_wave = has_read ? nt : 0; // the loop is the wavefront's: lanes past their read's end idle but still help
@@ -116,9 +143,15 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 		int cv_now = 0; // the suffix's count of the entering triplet, after it entered
 		int t = -1;
 		const bool mine = has_read && b < nt;
-		if (mine) {
+		if constexpr (REGS) {
 			if ((b & 15) == 0)
-				in_w = window64(rw, b);
+				in_w = reg_window64(R, b);
+		}
+		if (mine) {
+			if constexpr (!REGS) {
+				if ((b & 15) == 0)
+					in_w = window64(rw, b);
+			}
 			t = (int)(in_w & 63ull);
 			in_w >>= 2;
 			if (ra && (window64(ra, b) & 0x15ull))
@@ -126,43 +159,48 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			if (t < 0) { // a letter that is no base: no interval crosses it
 				for (int k = 0; k < 32; k++)
 					c32[k] = 0u;
-				size = L = rw_pairs = rv_pairs = 0;
+				size = L = rw_pairs = 0;
 			}
+		}
+		if constexpr (REGS) {
+			// (the leaving triplet's register: every lane whose window is full is at the same position b - 62)
+			if (b >= kDustMaxT && ((b - kDustMaxT) & 15) == 0)
+				out_w = reg_window64(R, b - kDustMaxT);
 		}
 		if (t >= 0) {
 		if (size >= kDustMaxT) {
 			// the oldest triplet leaves: position b - 62 (the window was full, so it is 62 triplets behind)
 			const int ob = b - kDustMaxT;
-			if (ob != out_pos || (ob & 15) == 0) {
-				out_w = window64(rw, ob);
-				out_pos = ob;
+			int s0;
+			if constexpr (REGS) {
+				s0 = (int)((out_w >> (2 * (ob & 15))) & 63ull);
+			} else {
+				if (ob != out_pos || (ob & 15) == 0) {
+					out_w = window64(rw, ob);
+					out_pos = ob;
+				}
+				s0 = (int)(out_w & 63ull);
+				out_w >>= 2;
+				out_pos++;
 			}
-			const int s0 = (int)(out_w & 63ull);
-			out_w >>= 2;
-			out_pos++;
 			// the leaving and the entering triplet in one go: four counters read together, then written (four dependent
 			// read-modify-writes of LDS bytes per position were the rest of this kernel's time).  Same triplet leaving and
-			// entering: the counts and both pair sums end where they were.
+			// entering: the counts and the pair sum end where they were.
 			const bool in_suffix = L > size - 1;
 			if (s0 != t) {
 				const int cw_s = ld.cw[s0], cv_s = ld.cv[s0], cw_t = ld.cw[t], cv_t = ld.cv[t];
 				ld.cw[s0] = (uint8_t)(cw_s - 1);
 				rw_pairs += cw_t - (cw_s - 1);
 				ld.cw[t] = (uint8_t)(cw_t + 1);
-				if (in_suffix) {
+				if (in_suffix)
 					ld.cv[s0] = (uint8_t)(cv_s - 1);
-					rv_pairs -= cv_s - 1;
-				}
-				rv_pairs += cv_t;
 				cv_now = cv_t + 1;
 				ld.cv[t] = (uint8_t)cv_now;
 			} else if (in_suffix) {
 				cv_now = ld.cv[t]; // (one out, one in)
 			} else {
 				// the leaving copy lies before the suffix: only the window's count is a wash, the suffix gains one
-				const int cv_t = ld.cv[t];
-				rv_pairs += cv_t;
-				cv_now = cv_t + 1;
+				cv_now = ld.cv[t] + 1;
 				ld.cv[t] = (uint8_t)cv_now;
 			}
 			if (!in_suffix)
@@ -172,77 +210,55 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 			L++;
 			const int cw_t = ld.cw[t], cv_t = ld.cv[t];
 			rw_pairs += cw_t;
-			rv_pairs += cv_t;
 			ld.cw[t] = (uint8_t)(cw_t + 1);
 			cv_now = cv_t + 1;
 			ld.cv[t] = (uint8_t)cv_now;
 		}
 		}
-		dust_wave_sync();
+		dust_wave_order();
 		// The suffix shrinks past the earliest copy of t when t now occurs more than 4 times in it.  Some lane of the 64 needs
 		// that at most positions, and a lane's own loop over up to 61 triplets (a counter read-modify-write each) held up
 		// the other 63: the WAVEFRONT shrinks one lane's suffix at a time -- lane j looks at the suffix's j-th triplet, a
-		// ballot finds the earliest copy, the removed triplets go into a 64-bin histogram, lane v settles triplet v's
-		// counter and its share of the pair sum (v leaves m times from a count of c: m c - m (m + 1) / 2 pairs fewer).
+		// ballot finds the earliest copy, and every lane up to it takes its triplet out of lane x's counters with ONE LDS
+		// atomic on the counter's word (a byte never borrows: the triplet is in the suffix).  Nothing waits: the LDS
+		// operations of a wavefront execute in the order they were issued, so lane x's next read of its counters sees
+		// them.  (Round 3 went through a 64-bin histogram: five LDS round trips per shrink, ~1 500 cycles per position.)
 		for (unsigned long long need = __ballot(cv_now * 10 > 2 * kDustLevel); need; need &= need - 1ull) {
 			const int x = __ffsll((unsigned long long)need) - 1, lane = (int)(threadIdx.x & 63);
-			const int xL = __shfl(L, x), xt = __shfl(t, x), xsp = b - xL + 1;
-			const uint64_t *xrw = reinterpret_cast<const uint64_t *>(
-				((unsigned long long)(uint32_t)__shfl((int)((uintptr_t)rw >> 32), x) << 32) | (uint32_t)__shfl((int)(uintptr_t)rw, x));
-			const int val = lane < xL ? (int)(window64(xrw, xsp + lane) & 63ull) : -1;
+			const int xL = __builtin_amdgcn_readlane(L, x), xt = __builtin_amdgcn_readlane(t, x), xsp = b - xL + 1;
+			int val = -1;
+			if constexpr (REGS) {
+				// the (at most four) words of lane x's read that hold the suffix, through scalar registers
+				const int w0 = xsp >> 5; // (the same in every lane)
+				uint64_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+#pragma unroll
+				for (int k = 0; k < NW; k++)
+					if (w0 == k) {
+						o0 = readlane64(R[k], x);
+						o1 = readlane64(R[k + 1], x);
+						o2 = readlane64(R[k + 2], x);
+						o3 = readlane64(R[k + 3], x);
+					}
+				const int p = xsp + lane, wi = (p >> 5) - w0, sh = (p & 31) * 2; // wi = 0, 1 or 2
+				const uint64_t lo = wi == 0 ? o0 : (wi == 1 ? o1 : o2), hi = wi == 0 ? o1 : (wi == 1 ? o2 : o3);
+				const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+				val = lane < xL ? (int)(w & 63ull) : -1;
+			} else {
+				const uint64_t *xrw = reinterpret_cast<const uint64_t *>(
+					((unsigned long long)(uint32_t)__shfl((int)((uintptr_t)rw >> 32), x) << 32) | (uint32_t)__shfl((int)(uintptr_t)rw, x));
+				val = lane < xL ? (int)(window64(xrw, xsp + lane) & 63ull) : -1;
+			}
 			const unsigned long long hit = __ballot(val == xt);
 			const int k = __ffsll((unsigned long long)hit) - 1; // the earliest copy (the entering one is in the suffix: there is one)
-			s_hist[lane] = 0u;
-			dust_wave_sync();
 			if (lane <= k)
-				atomicAdd(&s_hist[val], 1u);
-			dust_wave_sync();
-			const int m = (int)s_hist[lane];
-			int term = 0;
-			if (m) {
-				const int c = s_lane[x].cv[lane];
-				term = m * c - m * (m + 1) / 2;
-				s_lane[x].cv[lane] = (uint8_t)(c - m);
-			}
-			for (int sh = 1; sh < 64; sh <<= 1)
-				term += __shfl_xor(term, sh);
-			if (lane == x) {
-				rv_pairs -= term;
+				atomicSub(reinterpret_cast<uint32_t *>(s_lane[x].cv) + (val >> 2), 1u << (8 * (val & 3)));
+			if (lane == x)
 				L -= k + 1;
-			}
-			dust_wave_sync();
+			dust_wave_order();
 		}
-		if (!CONFIRM && t >= 0 && rw_pairs * 10 > L * kDustLevel) {
+		if (t >= 0 && rw_pairs * 10 > L * kDustLevel) {
 			first = first < 0 ? b : first;
 			last = b;
-		}
-		if constexpr (CONFIRM) {
-		if (t >= 0 && rw_pairs * 10 > L * kDustLevel) {
-			// the algorithm would now look at the suffixes LONGER than that suffix, longest last; an interval that scores
-			// above the level exists in the read exactly when one of these does somewhere (its best sub-interval is
-			// perfect), so this decides whether the read has a masked base at all
-			uint32_t *t32 = reinterpret_cast<uint32_t *>(ld.ct);
-			const uint32_t *v32 = reinterpret_cast<const uint32_t *>(ld.cv);
-			for (int k = 0; k < 16; k++)
-				t32[k] = v32[k];
-			int rr = rv_pairs;
-			int q0 = -64; // the walk goes DOWN the read: 30 triplets per 64-bit window of letters, taken with a shift
-			uint64_t qw = 0;
-			for (int k = size - L - 1; k >= 0; k--) {
-				const int q = b - size + 1 + k;
-				if (q < q0 || q > q0 + 29) {
-					q0 = q >= 29 ? q - 29 : 0;
-					qw = window64(rw, q0);
-				}
-				const int tt = (int)((qw >> (2 * (q - q0))) & 63ull); // (inside the window every triplet is one of bases)
-				rr += ld.ct[tt]++;
-				if (rr * 10 > kDustLevel * (size - k - 1)) {
-					first = first < 0 ? b : first;
-					last = b;
-					break;
-				}
-			}
-		}
 		}
 	}
 	// one atomic per wavefront (a single counter takes ~90 M atomics a second: one per listed read was most of this kernel)
@@ -261,90 +277,145 @@ __global__ __launch_bounds__(64) void k_dust_trigger(const uint64_t *__restrict_
 	}
 }
 
-__global__ __launch_bounds__(64) void k_dust_mask(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
-						   const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff,
-						   const uint32_t *__restrict__ list, const uint2 *__restrict__ range, const uint32_t *__restrict__ n_list,
-						   uint64_t *__restrict__ mask, uint8_t *__restrict__ any)
+// Second pass, ONE WAVEFRONT per listed read: the definition itself (header) on the stretch where the first pass's test
+// passed -- intervals [a, b] of at most 62 triplets with a >= first - 61 and b <= last -- as a dynamic programme over the
+// interval LENGTH: lane j holds the start a = a0 + j, step l every lane's interval [a, a + l - 1].
+//   pairs(a, b) = pairs(a + 1, b) + pairs(a, b - 1) - pairs(a + 1, b - 1) + [t_a = t_b]
+//   best(a, b)  = max(score(a, b), best(a + 1, b), best(a, b - 1))      (exact fractions, a missing score below all)
+// so a step needs lane j + 1's values of the two steps before (two DPP wave shifts) and the triplet at the interval's end
+// (a third); perfect = score above the level and no sub-interval higher; lane j keeps the furthest base its perfect
+// intervals reach.  More than 64 starts: chunks of 64 from the top, a chunk's lane 0 leaving its two sequences in LDS
+// for lane 63 of the chunk below.  Round 3 ran this stretch twice with ONE LANE per read -- a walk over the longer
+// suffixes at every position that passed (3.9 ms for 0.7 M reads), then the dynamic programme row by row on the reads
+// that survived (3.0 ms for 0.26 M) -- eleven and four thousand wavefronts of a hundred thousand instructions each on
+// a chip that holds sixteen thousand: 6.9 ms of a nearly empty machine.
+__device__ __forceinline__ int dust_dpp_up(int v, int last_lane_value) // lane j <- lane j + 1; lane 63 <- last_lane_value
 {
-	__shared__ DustLane s_lane[64];
-	DustLane &ld = s_lane[threadIdx.x];
-	const uint32_t at = blockIdx.x * 64u + threadIdx.x;
-	if (at >= *n_list)
-		return;
-	const uint32_t r = list[at];
-	const int L = (int)len[r], nt = L - 2;
-	const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
-	uint64_t *mw = mask + woff[r];
-	bool marked = false;
-	// perfect intervals end at a position that passed the trigger: [b_first, b_last]; they hold at most 62 triplets
-	const int b_hi = (int)range[at].y, a_lo = (int)range[at].x - (kDustMaxT - 1) > 0 ? (int)range[at].x - (kDustMaxT - 1) : 0;
-	for (int k = 0; k < kDustMaxT + 2; k++)
-		ld.row[k] = 0u;
-	// one row, updated in place: before the step for (a, b) row[b - a] holds the best of [a + 1, b + 1] and row[b - a - 1]
-	// the best of [a + 1, b] (the row below); the step leaves the best of [a, b] in row[b - a]
-	for (int a = b_hi < nt - 1 ? b_hi : nt - 1; a >= a_lo; a--) {
-		for (int k = 0; k < 16; k++)
-			reinterpret_cast<uint32_t *>(ld.cnt)[k] = 0u;
-		uint32_t rsum = 0, left = 0u, below_prev = 0u; // below_prev = row below at index b - a - 1 (saved before it is overwritten)
-		int b = a;
-		uint64_t fw = 0; // letters from b on, one letter further per step, refilled every 16 (any one-to-one naming of the
-				 // triplets serves the counters)
-		for (; b <= b_hi && b < nt && b - a < kDustMaxT; b++) {
-			if (b == a || ((b - a) & 15) == 0)
-				fw = window64(rw, b);
-			const int t = ra && (window64(ra, b) & 0x15ull) ? -1 : (int)(fw & 63ull);
-			fw >>= 2;
-			if (t < 0)
-				break;
-			rsum += ld.cnt[t]++;
-			const uint32_t q = (uint32_t)(b - a);
-			const uint32_t s = q ? (rsum | (q << 16)) : 0u;
-			const uint32_t old_here = ld.row[b - a]; // row below at index b - a: the next step's `below_prev`
-			uint32_t sub = left;
-			if (b > a && frac_gt(below_prev, sub))
-				sub = below_prev;
-			if (q && rsum * 10u > (uint32_t)kDustLevel * q && !frac_gt(sub, s)) {
-				// mask bases a .. b + 2 (this lane's own words)
+	return __builtin_amdgcn_update_dpp(last_lane_value, v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(64) void k_dust_perfect(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
+						      const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff,
+						      const uint32_t *__restrict__ list, const uint2 *__restrict__ range, const uint32_t *__restrict__ n_list,
+						      uint64_t *__restrict__ mask, uint8_t *__restrict__ any)
+{
+	// lane 0's sequences (pairs, best score as numerator and denominator; index = interval length) of the chunk above
+	__shared__ uint32_t s_up[3][64];
+	const int lane = (int)(threadIdx.x & 63);
+	const uint32_t n_in = *n_list;
+	for (uint32_t at = blockIdx.x; at < n_in; at += gridDim.x) {
+		const uint32_t r = list[at];
+		const int L = (int)len[r], nt = L - 2;
+		const uint64_t *rw = fwd + woff[r], *ra = amb ? amb + woff[r] : nullptr;
+		uint64_t *mw = mask + woff[r];
+		const int nw = (L + 63) >> 6;
+		for (int w = lane; w < nw; w += 64)
+			mw[w] = 0ull;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the words are zero before any lane ORs into them)
+		const int b_hi = (int)range[at].y < nt - 1 ? (int)range[at].y : nt - 1;
+		const int a_lo = (int)range[at].x - (kDustMaxT - 1) > 0 ? (int)range[at].x - (kDustMaxT - 1) : 0;
+		const int n_chunks = (b_hi - a_lo + 64) / 64;
+		bool marked = false;
+		for (int c = n_chunks - 1; c >= 0; c--) {
+			const int a0 = a_lo + 64 * c;
+			// this lane's triplet and the one 64 positions on (what lane 63's intervals reach), -1: none
+			auto triplet = [&](int p) -> int {
+				if (p >= nt || (ra && (window64(ra, p) & 0x15ull)))
+					return -1;
+				return (int)(window64(rw, p) & 63ull);
+			};
+			const int a = a0 + lane;
+			const int ta = triplet(a), t_far = triplet(a + 64);
+			const bool has_up = c + 1 < n_chunks; // (the top chunk's lane 63 has no neighbour: its longer intervals end past b_hi anyway)
+			const uint32_t upP = has_up ? s_up[0][lane] : 0u, upN = has_up ? s_up[1][lane] : 0u, upQ = has_up ? s_up[2][lane] : 1u;
+			dust_wave_sync(); // (read before this chunk's lane 0 replaces them)
+			bool live = a <= b_hi && ta >= 0;
+			int tb = ta;
+			// pairs of the two steps before; best score of the step before as a fraction Bn / Bq (no score yet = 0 / 1: below or
+			// equal to every score, and the level test never passes with zero pairs)
+			uint32_t P1 = 0, P2 = 0, Bn = 0, Bq = 1;
+			uint32_t myP = 0, myN = 0, myQ = 1; // lane l: lane 0's values at length l
+			int end = -1;                       // furthest base a perfect interval of this start covers
+			const int l_max = b_hi - a0 + 1 < kDustMaxT ? b_hi - a0 + 1 : kDustMaxT; // (lane 0's reach; the other lanes die earlier)
+			for (int l = 2; l <= l_max; l++) {
+				// lane j + 1's registers before this step: its pairs at l - 1 and l - 2, its best at l - 1, its end triplet;
+				// lane 63's neighbour is lane 0 of the chunk above
+				const uint32_t nP1 = (uint32_t)dust_dpp_up((int)P1, __builtin_amdgcn_readlane((int)upP, l - 1));
+				const uint32_t nP2 = (uint32_t)dust_dpp_up((int)P2, l > 2 ? __builtin_amdgcn_readlane((int)upP, l - 2) : 0);
+				const uint32_t nBn = (uint32_t)dust_dpp_up((int)Bn, __builtin_amdgcn_readlane((int)upN, l - 1));
+				const uint32_t nBq = (uint32_t)dust_dpp_up((int)Bq, __builtin_amdgcn_readlane((int)upQ, l - 1));
+				tb = dust_dpp_up(tb, __builtin_amdgcn_readlane(t_far, l - 2)); // position a0 + 63 + l - 1
+				live = live && tb >= 0 && a + l - 1 <= b_hi;
+				const uint32_t P = P1 + nP1 - nP2 + (tb == ta ? 1u : 0u);
+				const uint32_t q = (uint32_t)(l - 1);
+				// the better of the two sub-interval bests: [a, b - 1] (this lane, the step before) and [a + 1, b] (lane j + 1)
+				const bool up_better = __umul24(nBn, Bq) > __umul24(Bn, nBq);
+				const uint32_t sn = up_better ? nBn : Bn, sq = up_better ? nBq : Bq;
+				const uint32_t lhs = __umul24(sn, q), rhs = __umul24(P, sq); // sub > score <=> lhs > rhs
+				if (live && P * 10u > (uint32_t)kDustLevel * q && lhs <= rhs)
+					end = a + l + 1; // bases a .. b + 2, b = a + l - 1
+				const bool sc_better = rhs > lhs;
+				P2 = P1;
+				P1 = live ? P : 0u;
+				Bn = live ? (sc_better ? P : sn) : 0u;
+				Bq = live ? (sc_better ? q : sq) : 1u;
+				if (c > 0) { // (somebody below will ask)
+					// (lane 0's values first, in statements of their own: inside the conditional operand they would be
+					// read under the branch's execution mask -- from lane l itself)
+					const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)P1, 0), n0 = (uint32_t)__builtin_amdgcn_readlane((int)Bn, 0),
+						       q0 = (uint32_t)__builtin_amdgcn_readlane((int)Bq, 0);
+					const bool me = lane == l;
+					myP = me ? p0 : myP;
+					myN = me ? n0 : myN;
+					myQ = me ? q0 : myQ;
+				}
+			}
+			if (c > 0) {
+				s_up[0][lane] = myP;
+				s_up[1][lane] = myN;
+				s_up[2][lane] = myQ;
+				dust_wave_sync();
+			}
+			if (end >= 0) {
 				marked = true;
-				for (int k = a; k <= b + 2;) {
+				for (int k = a; k <= end;) {
 					const int w = k >> 6, lo = k & 63;
-					const int hi = (b + 2 - (w << 6)) < 63 ? b + 2 - (w << 6) : 63;
+					const int hi = (end - (w << 6)) < 63 ? end - (w << 6) : 63;
 					const uint64_t bits = (hi == 63 ? ~0ull : ((2ull << hi) - 1ull)) & (~0ull << lo);
-					mw[w] |= bits;
+					atomicOr(reinterpret_cast<unsigned long long *>(mw + w), (unsigned long long)bits);
 					k = (w + 1) << 6;
 				}
 			}
-			const uint32_t best = frac_gt(s, sub) ? s : sub;
-			ld.row[b - a] = best;
-			left = best;
-			below_prev = old_here;
 		}
-		for (int k = b - a; k <= kDustMaxT; k++)
-			ld.row[k] = 0u;
+		if (__ballot(marked) && lane == 0)
+			any[r] = 1;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
-	any[r] = marked ? 1 : 0;
 }
 
-// window bits of both strands: bit i of dustwin_f[read]: bases i .. i + 27 of the read hold no masked base (and i + 28 <= L);
-// dustwin_r the same for the reverse-complement strand (its mask is the forward mask reversed)
+// window bits of both strands of the LISTED reads that hold a masked base: bit i of dustwin_f[read]: bases i .. i + 27 of
+// the read hold no masked base (and i + 28 <= L); dustwin_r the same for the reverse-complement strand (its mask is the
+// forward mask reversed).  The seed stage looks at the words of reads with any[read] != 0 only, so the words of the other
+// reads are never written (round 3 wrote -- and cleared -- all of them: 2 GB per 10 M reads).
 __global__ void k_dust_windows(const uint64_t *__restrict__ mask, const uint8_t *__restrict__ any, const uint32_t *__restrict__ len,
-			       const uint32_t *__restrict__ woff, uint32_t n, uint64_t *__restrict__ win_f, uint64_t *__restrict__ win_r)
+			       const uint32_t *__restrict__ woff, const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
+			       uint64_t *__restrict__ win_f, uint64_t *__restrict__ win_r)
 {
-	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n)
-		return;
-	const int L = (int)len[r];
-	const uint32_t w0 = woff[r];
-	const int nw = (L + 63) >> 6;
-	const int n_valid = L - kWord + 1; // window positions 0 .. n_valid - 1
-	const bool dirty = any[r] != 0;
-	auto valid_bits = [&](int w) -> uint64_t { // positions of word w below n_valid
-		const int left = n_valid - (w << 6);
-		return left <= 0 ? 0ull : (left >= 64 ? ~0ull : ((1ull << left) - 1ull));
-	};
-	for (int w = 0; w < nw; w++) {
-		uint64_t f = valid_bits(w);
-		if (dirty) {
+	const uint32_t n_in = *n_list;
+	for (uint32_t at = blockIdx.x * blockDim.x + threadIdx.x; at < n_in; at += gridDim.x * blockDim.x) {
+		const uint32_t r = list[at];
+		if (!any[r])
+			continue;
+		const int L = (int)len[r];
+		const uint32_t w0 = woff[r];
+		const int nw = (L + 63) >> 6;
+		const int n_valid = L - kWord + 1; // window positions 0 .. n_valid - 1
+		auto valid_bits = [&](int w) -> uint64_t { // positions of word w below n_valid
+			const int left = n_valid - (w << 6);
+			return left <= 0 ? 0ull : (left >= 64 ? ~0ull : ((1ull << left) - 1ull));
+		};
+		for (int w = 0; w < nw; w++) {
+			uint64_t f = valid_bits(w);
 			// a window is spoilt by a masked base at any of its 28 positions: OR of the mask moved down by 0 .. 27, in log
 			// steps on the 128 bits that start at this word (2, 4, 8, 16 wide, then 16 + 8 + 4)
 			uint64_t lo = mask[w0 + w], hi = w + 1 < nw ? mask[w0 + w + 1] : 0ull;
@@ -352,24 +423,19 @@ __global__ void k_dust_windows(const uint64_t *__restrict__ mask, const uint8_t 
 				a |= (a >> k) | (b << (64 - k));
 				b |= b >> k;
 			};
-			shr(lo, hi, 1);
-			const uint64_t l2 = lo, h2 = hi; // covers 2
-			shr(lo, hi, 2);
-			const uint64_t l4 = lo, h4 = hi; // covers 4
-			shr(lo, hi, 4);
-			const uint64_t l8 = lo, h8 = hi; // covers 8
+			shr(lo, hi, 1); // covers 2
+			shr(lo, hi, 2); // covers 4
+			const uint64_t l4 = lo, h4 = hi;
+			shr(lo, hi, 4); // covers 8
+			const uint64_t l8 = lo, h8 = hi;
 			shr(lo, hi, 8); // covers 16
-			(void)l2;
-			(void)h2;
 			const uint64_t d = lo | ((l8 >> 16) | (h8 << 48)) | ((l4 >> 24) | (h4 << 40)); // 16 + 8 + 4 = 28
 			f &= ~d;
+			win_f[w0 + w] = f;
 		}
-		win_f[w0 + w] = f;
-	}
-	// the reverse-complement strand: its window i is the forward window n_valid - 1 - i
-	for (int w = 0; w < nw; w++) {
-		uint64_t rv = valid_bits(w);
-		if (dirty) {
+		// the reverse-complement strand: its window i is the forward window n_valid - 1 - i
+		for (int w = 0; w < nw; w++) {
+			uint64_t rv = valid_bits(w);
 			// forward positions n_valid - 64 w - 64 .. n_valid - 64 w - 1, reversed
 			const int s0 = n_valid - (w << 6) - 64;
 			uint64_t span;
@@ -383,110 +449,47 @@ __global__ void k_dust_windows(const uint64_t *__restrict__ mask, const uint8_t 
 				span = 0ull;
 			}
 			rv = __brevll(span);
-		}
-		win_r[w0 + w] = rv;
-	}
-}
-
-// The second trigger pass and the mask kernel run one lane per LISTED read, and a lane's work grows with the stretch of
-// positions that passed the pass before (last - first): the suffix walks there, the rows of the dynamic programme here.  A
-// wavefront runs as long as its longest lane, so the lists are ordered by that length first, longest first (a counting sort,
-// 256 buckets, order inside a bucket left open: the kernels behind treat every read on its own).  k_dust_mask: 6.1 -> see
-// DESIGN section 7.
-__global__ __launch_bounds__(256) void k_dust_order_hist(const uint2 *__restrict__ range, const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ hist)
-{
-	__shared__ uint32_t h[256];
-	h[threadIdx.x] = 0;
-	__syncthreads();
-	const uint32_t n = *n_ptr;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-		const uint2 r = range[i];
-		const uint32_t k = r.y - r.x;
-		atomicAdd(&h[k < 255u ? k : 255u], 1u);
-	}
-	__syncthreads();
-	if (h[threadIdx.x])
-		atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-// hist[0 .. 255] -> hist[256 + k] = entries with a longer range than k (where bucket k starts)
-__global__ __launch_bounds__(256) void k_dust_order_bases(uint32_t *__restrict__ hist)
-{
-	if (threadIdx.x == 0) {
-		uint32_t run = 0;
-		for (int k = 255; k >= 0; k--) {
-			hist[256 + k] = run;
-			run += hist[k];
+			win_r[w0 + w] = rv;
 		}
 	}
 }
 
-__global__ __launch_bounds__(256) void k_dust_order_scatter(const uint32_t *__restrict__ list, const uint2 *__restrict__ range,
-							    const uint32_t *__restrict__ n_ptr, uint32_t *__restrict__ hist, uint32_t *__restrict__ list_out,
-							    uint2 *__restrict__ range_out)
+// One DUST pass over a batch on `stream`, into `b`: the first pass over every read, the definition on the listed reads, the
+// window bits of the reads with a masked base.  No host wait: the kernels behind the first pass take the list's length
+// on the device.
+static int dust_pass(const pgx_reads *rd, DustBufs &b, hipStream_t stream)
 {
-	// per tile of 2 048 entries: bucket counts in LDS, ONE global atomic per bucket and tile (most entries share a handful of
-	// buckets, and a single address takes ~90 M atomics a second), places inside the tile from LDS atomics
-	__shared__ uint32_t h[256], at[256];
-	const uint32_t n = *n_ptr;
-	for (uint32_t t0 = blockIdx.x * 2048u; t0 < n; t0 += gridDim.x * 2048u) {
-		h[threadIdx.x] = 0;
-		__syncthreads();
-		uint2 r[8];
-		uint32_t k[8];
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const uint32_t i = t0 + q * 256u + threadIdx.x;
-			r[q] = i < n ? range[i] : make_uint2(0u, 0u);
-			k[q] = r[q].y - r[q].x;
-			k[q] = k[q] < 255u ? k[q] : 255u;
-			if (i < n)
-				atomicAdd(&h[k[q]], 1u);
-		}
-		__syncthreads();
-		at[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&hist[256 + threadIdx.x], h[threadIdx.x]) : 0u;
-		__syncthreads();
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const uint32_t i = t0 + q * 256u + threadIdx.x;
-			if (i < n) {
-				const uint32_t o = atomicAdd(&at[k[q]], 1u);
-				list_out[o] = list[i];
-				range_out[o] = r[q];
-			}
-		}
-		__syncthreads();
-	}
-}
-
-// list / range (n entries, count on the device) -> list_s / range_s in the order above
-static int dust_order(DustBufs &b, const uint32_t *list, const uint2 *range, const uint32_t *n_ptr, size_t n_max, hipStream_t stream)
-{
-	if (n_max == 0)
-		return 0;
-	PGX_HIP(hipMemsetAsync(b.hist.data(), 0, 512 * sizeof(uint32_t), stream));
-	const unsigned grid = (unsigned)std::min<size_t>((n_max + 2047) / 2048, 256 * 8);
-	hipLaunchKernelGGL(k_dust_order_hist, dim3(grid), dim3(256), 0, stream, range, n_ptr, b.hist.data());
-	hipLaunchKernelGGL(k_dust_order_bases, dim3(1), dim3(64), 0, stream, b.hist.data());
-	hipLaunchKernelGGL(k_dust_order_scatter, dim3(grid), dim3(256), 0, stream, list, range, n_ptr, b.hist.data(), b.list_s.data(),
-			   b.range_s.data());
-	PGX_HIP(hipGetLastError());
-	return 0;
-}
-
-// buffers of a pass over a batch of n reads, n_mask window words; `listed` = what the second list needs (0: not known yet)
-static int dust_bufs_ensure(DustBufs &b, size_t n, size_t n_mask, size_t listed)
-{
+	const size_t n = (size_t)rd->n;
+	const size_t n_mask = (size_t)rd->n_words + 24;
 	PGX_TRY(b.mask.ensure(n_mask));
+	PGX_TRY(b.win_f.ensure(n_mask));
+	PGX_TRY(b.win_r.ensure(n_mask));
 	PGX_TRY(b.any.ensure(n));
 	PGX_TRY(b.list.ensure(n));
 	PGX_TRY(b.range.ensure(n));
-	PGX_TRY(b.list_s.ensure(n));
-	PGX_TRY(b.range_s.ensure(n));
-	PGX_TRY(b.hist.ensure(512));
 	PGX_TRY(b.n.ensure(2));
-	if (listed)
-		PGX_TRY(b.list2.ensure(listed));
+	PGX_HIP(hipMemsetAsync(b.any.data(), 0, n, stream));
+	PGX_HIP(hipMemsetAsync(b.n.data(), 0, 2 * sizeof(uint32_t), stream));
+	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
+	const dim3 g((unsigned)((n + 63) / 64)), blk(64);
+#define PGX_DUST_SCAN(NW)                                                                                                                \
+	hipLaunchKernelGGL(k_dust_scan<NW>, g, blk, 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, \
+			   b.list.data(), b.range.data(), b.n.data())
+	if (amb || rd->max_len > 512)
+		PGX_DUST_SCAN(0);
+	else if (rd->max_len <= 192)
+		PGX_DUST_SCAN(6);
+	else if (rd->max_len <= 320)
+		PGX_DUST_SCAN(10);
+	else
+		PGX_DUST_SCAN(16);
+#undef PGX_DUST_SCAN
+	const unsigned grid2 = (unsigned)std::min<size_t>(n, 256 * 32);
+	hipLaunchKernelGGL(k_dust_perfect, dim3(grid2), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(), rd->d_woff.data(), b.list.data(),
+			   b.range.data(), b.n.data(), b.mask.data(), b.any.data());
+	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)std::min<size_t>((n + 127) / 128, 256 * 8)), dim3(128), 0, stream, b.mask.data(), b.any.data(),
+			   rd->d_len.data(), rd->d_woff.data(), b.list.data(), b.n.data(), b.win_f.data(), b.win_r.data());
+	PGX_HIP(hipGetLastError());
 	return 0;
 }
 
@@ -498,36 +501,10 @@ int reads_dust(pgx_reads *rd)
 	if (n == 0)
 		return 0;
 	DustBufs &b = rd->dustb;
-	const size_t n_mask = (size_t)rd->n_words + 24;
-	PGX_TRY(dust_bufs_ensure(b, n, n_mask, 0));
-	PGX_HIP(hipMemsetAsync(b.mask.data(), 0, n_mask * sizeof(uint64_t), 0));
-	PGX_HIP(hipMemsetAsync(b.any.data(), 0, n, 0));
-	PGX_HIP(hipMemsetAsync(b.n.data(), 0, 2 * sizeof(uint32_t), 0));
-	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
-	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b.list.data(), b.range.data(),
-			   b.n.data());
-	PGX_HIP(hipGetLastError());
-	uint32_t n_listed[2] = { 0, 0 };
-	PGX_TRY(b.n.download(n_listed, 1));
-	if (n_listed[0]) {
-		PGX_TRY(b.list2.ensure(n_listed[0]));
-		PGX_TRY(dust_order(b, b.list.data(), b.range.data(), b.n.data(), n_listed[0], 0));
-		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((n_listed[0] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.list_s.data(), b.n.data(), b.list2.data(), b.range.data(),
-				   b.n.data() + 1);
-		PGX_HIP(hipGetLastError());
-		PGX_TRY(b.n.download(n_listed, 2));
-	}
-	if (n_listed[1]) {
-		PGX_TRY(dust_order(b, b.list2.data(), b.range.data(), b.n.data() + 1, n_listed[1], 0));
-		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((n_listed[1] + 63) / 64)), dim3(64), 0, 0, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), b.list_s.data(), b.range_s.data(), b.n.data() + 1, b.mask.data(), b.any.data());
-		PGX_HIP(hipGetLastError());
-	}
+	PGX_TRY(dust_pass(rd, b, 0));
 	std::vector<uint8_t> &h_any = rd->h_read_dust;
 	h_any.resize(n);
-	PGX_TRY(b.any.download(h_any.data(), n));
+	PGX_TRY(b.any.download(h_any.data(), n)); // (waits for the pass)
 	bool some = false;
 	for (size_t i = 0; i < n && !some; i++)
 		some = h_any[i] != 0;
@@ -535,62 +512,19 @@ int reads_dust(pgx_reads *rd)
 		h_any.clear();
 		return 0; // no read of the batch has a masked base: the seed stage runs as without DUST
 	}
-	PGX_TRY(b.win_f.ensure(n_mask));
-	PGX_TRY(b.win_r.ensure(n_mask));
-	PGX_HIP(hipMemsetAsync(b.win_f.data(), 0, n_mask * sizeof(uint64_t), 0));
-	PGX_HIP(hipMemsetAsync(b.win_r.data(), 0, n_mask * sizeof(uint64_t), 0));
-	hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, b.mask.data(), b.any.data(), rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, b.win_f.data(), b.win_r.data());
-	PGX_HIP(hipGetLastError());
-	PGX_HIP(hipDeviceSynchronize());
 	rd->has_dust = true;
-	rd->dust_listed[0] = n_listed[0];
-	rd->dust_listed[1] = n_listed[1];
 	return 0;
 }
 
-// The same passes again over a resident batch, on `stream`, without a host wait, INTO THE CALLER'S BUFFERS: S3d as part of a
+// The same pass again over a resident batch, on `stream`, without a host wait, INTO THE CALLER'S BUFFERS: S3d as part of a
 // search (BLAST masks its queries inside every search; `pgx_db_set_dust_each_search`).  The batch is only read: the buffers
 // belong to the searching handle's workspace, so searches of one batch through two handles do not meet.  The
-// masks depend on the reads alone, so the launch sizes the import's pass found (and the search classes made from its
-// per-read flags) hold; the kernels take their counts on the device.
+// masks depend on the reads alone, so the search classes made from the import's per-read flags hold.
 int reads_dust_again(const pgx_reads *rd, DustBufs &b, hipStream_t stream)
 {
-	const size_t n = (size_t)rd->n;
-	if (n == 0 || !rd->dustb.mask.base)
+	if (rd->n == 0)
 		return 0;
-	const size_t n_mask = (size_t)rd->n_words + 24;
-	PGX_TRY(dust_bufs_ensure(b, n, n_mask, rd->dust_listed[0]));
-	if (rd->has_dust) {
-		PGX_TRY(b.win_f.ensure(n_mask));
-		PGX_TRY(b.win_r.ensure(n_mask));
-	}
-	PGX_HIP(hipMemsetAsync(b.mask.data(), 0, n_mask * sizeof(uint64_t), stream));
-	PGX_HIP(hipMemsetAsync(b.any.data(), 0, n, stream));
-	PGX_HIP(hipMemsetAsync(b.n.data(), 0, 2 * sizeof(uint32_t), stream));
-	const uint64_t *amb = rd->has_amb ? rd->d_fwd_amb.data() : (const uint64_t *)nullptr;
-	hipLaunchKernelGGL(k_dust_trigger<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
-			   rd->d_woff.data(), (uint32_t)n, (const uint32_t *)nullptr, (const uint32_t *)nullptr, b.list.data(),
-			   b.range.data(), b.n.data());
-	if (rd->dust_listed[0]) {
-		PGX_TRY(dust_order(b, b.list.data(), b.range.data(), b.n.data(), rd->dust_listed[0], stream));
-		hipLaunchKernelGGL(k_dust_trigger<true>, dim3((unsigned)((rd->dust_listed[0] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb,
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.list_s.data(), b.n.data(), b.list2.data(),
-				   b.range.data(), b.n.data() + 1);
-	}
-	if (rd->dust_listed[1]) {
-		PGX_TRY(dust_order(b, b.list2.data(), b.range.data(), b.n.data() + 1, rd->dust_listed[1], stream));
-		hipLaunchKernelGGL(k_dust_mask, dim3((unsigned)((rd->dust_listed[1] + 63) / 64)), dim3(64), 0, stream, rd->d_fwd.data(), amb, rd->d_len.data(),
-				   rd->d_woff.data(), b.list_s.data(), b.range_s.data(), b.n.data() + 1, b.mask.data(), b.any.data());
-	}
-	if (rd->has_dust) {
-		PGX_HIP(hipMemsetAsync(b.win_f.data(), 0, n_mask * sizeof(uint64_t), stream));
-		PGX_HIP(hipMemsetAsync(b.win_r.data(), 0, n_mask * sizeof(uint64_t), stream));
-		hipLaunchKernelGGL(k_dust_windows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, b.mask.data(), b.any.data(),
-				   rd->d_len.data(), rd->d_woff.data(), (uint32_t)n, b.win_f.data(), b.win_r.data());
-	}
-	PGX_HIP(hipGetLastError());
-	return 0;
+	return dust_pass(rd, b, stream);
 }
 
 } // namespace pgx

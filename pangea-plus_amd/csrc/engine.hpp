@@ -79,12 +79,11 @@ namespace pgx {
 // given, so two handles may search one batch from two threads.
 struct DustBufs {
 	DevBuf<uint64_t> win_f, win_r; // per strand one bit per read position: the 28 bases from there touch no masked base
-	DevBuf<uint8_t> any;            // per read: it has a masked base (the others skip the window bits)
-	DevBuf<uint64_t> mask;
-	DevBuf<uint32_t> list, list2, n;
-	DevBuf<uint2> range;
-	DevBuf<uint32_t> list_s, hist; // a list ordered by the length of its entries' ranges; the 256 + 256 counters of that sort
-	DevBuf<uint2> range_s;
+				       // (written for the reads with a masked base only: nobody looks at the others' words)
+	DevBuf<uint8_t> any;            // per read: it has a masked base
+	DevBuf<uint64_t> mask;          // the masked bases of the listed reads
+	DevBuf<uint32_t> list, n;       // reads the first pass listed, their number (on the device)
+	DevBuf<uint2> range;            // first and last position of a listed read at which the algorithm's test passes
 };
 } // namespace pgx
 
@@ -118,7 +117,6 @@ struct pgx_reads {
 	// spec v2 S3d (dust.hip): per strand one bit per read position: the 28 bases from there on touch no base that DUST
 	// masks; 64 positions per word at the read's word offset; absent when no read of the batch has a masked base
 	bool has_dust = false;
-	uint32_t dust_listed[2] = { 0, 0 }; // reads the first / second trigger pass listed when the batch was made
 	pgx::DustBufs dustb; // what the batch's own DUST pass (at import; pgx_reads_redo_dust) wrote
 	pgx::DevBuf<uint32_t> d_len, d_woff; // d_woff has n+1 entries
 	// reads with a run of 6 or more unknown letters (mates joined by N's, Trim/trim2.4.pl:228-245) are searched as the

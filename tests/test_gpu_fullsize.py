@@ -111,6 +111,45 @@ def test_full_size_properties(full):
     assert (tail[rowmask[off[n // 2]:]] == h2[mask2]).all()
 
 
+def test_bench_size_batch_equals_oracle_chain_in_three_windows(full, oracle_bin):
+    """Config 3 at the size the metric is quoted on: ONE resident batch of 10 M reads of the bench's
+    stream, ONE `classify_consensus` with DUST inside the search -- the launch in which the region-ordered slot list, the
+    round counter handed out eight at a time and the 10 M-read table sizes run as benched -- then the rows and consensus
+    records of three 20 000-read windows (start, middle, end of the batch) against the checker's chain on the same reads,
+    byte for byte: `-outfmt 6` text and Consensus text.  The capacity guesses hold at this size (one attempt) and the
+    table's slot total equals the sum of the per-read slot counts."""
+    pg, _capi, cfg, db, d = full
+    n, win = 10_000_000, 20_000
+    db.set_dust_each_search(True)
+    try:
+        reads = pg.Reads.from_synth(cfg, 0, n)
+        rdp = pg.Rdp.from_synth(cfg, 0, n, db)
+        hits, recs = _capi.classify_consensus(db, reads, rdp)
+    finally:
+        db.set_dust_each_search(False)
+    st = _capi.stage_times()
+    assert st.attempts == 1 and st.dust_ms > 0
+    off = hits.read_offsets(n)
+    assert off[-1] == len(hits) == st.hits and 250_000_000 < st.hits < 320_000_000
+    del reads, rdp
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.o_bench_chain_files.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p,
+                                        C.c_char_p]
+    oc = OCfg(cfg.seed, cfg.n_seq, cfg.seq_len, cfg.n_genus, cfg.read_seed, cfg.read_len)
+    for first in (0, n // 2 - win // 2, n - win):
+        res = ORes()
+        hits_p, cons_p = str(d / ("w%d_hits.tsv" % first)), str(d / ("w%d_cons.txt" % first))
+        assert lib.o_bench_chain_files(C.byref(oc), first, win, min(os.cpu_count() or 1, 16), str(d).encode(), C.byref(res),
+                                       hits_p.encode(), cons_p.encode()) == 0
+        w_reads = pg.Reads.from_synth(cfg, first, win)
+        w_hits = hits.slice(first, win)
+        w_recs = recs[first:first + win].copy()
+        w_recs["hit"][w_recs["hit"] >= 0] -= off[first]
+        assert res.hits == w_hits.read_counts(win).sum() > 300000, first
+        assert w_hits.format(db, w_reads) == open(hits_p, "rb").read(), first
+        assert _capi.consensus_format(db, w_reads, w_hits, w_recs) == open(cons_p, "rb").read(), first
+
+
 def test_three_gigabase_database_uses_32_bit_positions(oracle_bin, tmp_path):
     """3.0 Gbp (2 000 001 x 1 500 bp): database positions above 2^31.  Reads are drawn from the whole database, so about a
     third of the hits lie in the upper part; -outfmt 6 table and consensus text against the oracle chain, byte for byte."""
