@@ -23,6 +23,8 @@
 //                 last triplet b ascending) restricted to intervals that end at or before the last such position and
 //                 start at most 61 triplets before the first; triplet counts and one row of best sub-interval scores in LDS
 // k_dust_windows  one lane per (read, 64 positions): the window bits of both strands from the mask
+#include <type_traits>
+
 #include "bitops.hpp"
 #include "engine.hpp"
 
@@ -62,20 +64,14 @@ __device__ __forceinline__ void dust_wave_sync()
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
-// the same for operations that only have to STAY in program order (the LDS unit takes a wavefront's operations in the order
-// they were issued): nothing to wait for, the compiler just may not move memory operations across
-__device__ __forceinline__ void dust_wave_order()
-{
-	asm volatile("" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-}
-
-// an odd word stride per lane: an even one put the 64 lanes' counters on two LDS banks (32-way conflicts)
-struct TrigLane {
-	uint8_t cw[64], cv[64];
+// One 32-bit word per triplet value and lane: bits 24-29 the value's count in the window of the last 62 triplets, bits
+// 0-23 the positions (mod 64) of its last four occurrences, newest in the low six bits.  65 words per lane: an odd stride
+// (an even one puts the 64 lanes' words on two LDS banks).
+struct ScanLane {
+	uint32_t w[64];
 	uint32_t pad;
 };
-static_assert(sizeof(TrigLane) / 4 % 2 == 1, "odd word stride");
+static_assert(sizeof(ScanLane) / 4 % 2 == 1, "odd word stride");
 
 // 64 bits of a read held in registers (R[k] = its k-th word, R[NW] .. = 0), from base `pos`; `pos` is the same in every lane
 template <int NR> __device__ __forceinline__ uint64_t reg_window64(const uint64_t (&R)[NR], int pos)
@@ -91,33 +87,32 @@ template <int NR> __device__ __forceinline__ uint64_t reg_window64(const uint64_
 	return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane_uniform)
-{
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
-	return ((uint64_t)hi << 32) | lo;
-}
-
-// First pass, every read of the batch, one lane per read: the published algorithm's own bookkeeping and its test
-// "10 r_w > 20 L" (header).  Lists the reads with a position that passes, with the first and last such position.
+// First pass, every read of the batch, one lane per read: the published algorithm's window bookkeeping and its test
+// "10 r_w > 20 L" (header), without which it never looks for a perfect interval ending at a position.  Lists the reads with
+// a position that passes, with the first and last such position.
+//   r_w  pairs of equal triplets in the window of the last (at most) 62 triplets: the entering triplet adds its count, the
+//        leaving one takes its count - 1 away.
+//   L    length of the window's longest suffix in which no triplet occurs more than 4 times.  Only the ENTERING triplet can
+//        move that suffix's start: to just behind its own fifth-most-recent occurrence, if that lies inside the window --
+//        which the triplet's window count says (5 or more with the entering one) and the triplet's last four positions
+//        give.  Both live in ONE LDS word per triplet value (ScanLane): a position costs two reads and two writes.
+//        Round 3 kept a second set of counters for the suffix and, when a count there reached 5, walked the suffix for its
+//        earliest copy -- the whole wavefront for one lane's walk, some lane at most positions: ~1 500 cycles a position.
 // NW > 0: reads of at most 32 NW bases without ambiguity letters, the whole read in NW 64-bit registers per lane -- no
-// memory access inside the loop.  Round 3's form (NW = 0: any length, ambiguity flags) fetched the letters of a suffix it
-// shrinks from memory, one dependent trip per shrink, and some lane shrinks at most positions: the kernel ran at the
-// latency of that load (4.0 ms per 10 M reads of 150 bases).
+// memory access inside the loop; NW = 0: any length, ambiguity flags, letters from memory every 16 positions.
 template <int NW>
 __global__ __launch_bounds__(64) void k_dust_scan(const uint64_t *__restrict__ fwd, const uint64_t *__restrict__ amb,
 						   const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, uint32_t n,
 						   uint32_t *__restrict__ list, uint2 *__restrict__ range, uint32_t *__restrict__ n_list)
 {
 	constexpr bool REGS = NW > 0;
-	constexpr int NR = REGS ? NW + 4 : 1;
-	__shared__ TrigLane s_lane[64];
-	TrigLane &ld = s_lane[threadIdx.x];
+	constexpr int NR = REGS ? NW + 1 : 1;
+	__shared__ ScanLane s_lane[64];
+	uint32_t *tab = s_lane[threadIdx.x].w;
 	const uint32_t at0 = blockIdx.x * 64u + threadIdx.x;
-	// (every lane runs the loop: the wavefront shrinks suffixes together; a lane past the end has no read)
 	const bool has_read = at0 < n;
 	const uint32_t r = has_read ? at0 : 0u;
-	const int nt = (int)len[r] - 2;
+	const int nt = has_read ? (int)len[r] - 2 : 0;
 	const uint64_t *rw = fwd + woff[r], *ra = (!REGS && amb) ? amb + woff[r] : nullptr;
 	uint64_t R[NR];
 	if constexpr (REGS) {
@@ -125,140 +120,88 @@ __global__ __launch_bounds__(64) void k_dust_scan(const uint64_t *__restrict__ f
 		for (int k = 0; k < NR; k++)
 			R[k] = k < NW ? rw[k] : 0ull; // (the packed reads carry spare words behind every read)
 	}
-	uint32_t *c32 = reinterpret_cast<uint32_t *>(&ld);
-	for (int k = 0; k < 32; k++)
-		c32[k] = 0u;
+	for (int k = 0; k < 64; k++)
+		tab[k] = 0u;
 	int first = -1, last = -1;
-	int size = 0, L = 0, rw_pairs = 0; // the window is the `size` triplets that end at the current one
-	// the entering and the leaving triplet come from two 64-bit registers that hold the next 32 letters each and move on
-	// by one letter per position (refilled every 16 positions)
+	int size = 0, start = 0, rw_pairs = 0; // the window is the `size` triplets that end at the current one; the suffix starts at `start`
+	// the entering and the leaving triplet come from two 64-bit registers that hold 32 letters each (refilled every 16 positions)
 	uint64_t in_w = 0, out_w = 0;
 	int out_pos = -1;
-	int nt_wave = has_read ? nt : 0; // the loop is the wavefront's: lanes past their read's end idle but still help
-	for (int sh = 1; sh < 64; sh <<= 1) {
-		const int o = __shfl_xor(nt_wave, sh);
-		nt_wave = o > nt_wave ? o : nt_wave;
+	int nt_wave = nt; // (REGS: the refills are the wavefront's, every lane runs to the longest read's end)
+	if constexpr (REGS) {
+		for (int sh = 1; sh < 64; sh <<= 1) {
+			const int o = __shfl_xor(nt_wave, sh);
+			nt_wave = o > nt_wave ? o : nt_wave;
+		}
 	}
 	for (int b = 0; b < nt_wave; b++) {
-		int cv_now = 0; // the suffix's count of the entering triplet, after it entered
 		int t = -1;
-		const bool mine = has_read && b < nt;
 		if constexpr (REGS) {
 			if ((b & 15) == 0)
 				in_w = reg_window64(R, b);
+			if (b >= kDustMaxT && ((b - kDustMaxT) & 15) == 0)
+				out_w = reg_window64(R, b - kDustMaxT); // (every lane whose window is full is at the same position b - 62)
 		}
-		if (mine) {
-			if constexpr (!REGS) {
+		if (b < nt) {
+			if constexpr (REGS) {
+				t = (int)((in_w >> (2 * (b & 15))) & 63ull);
+			} else {
 				if ((b & 15) == 0)
 					in_w = window64(rw, b);
+				t = (int)(in_w & 63ull);
+				in_w >>= 2;
+				if (ra && (window64(ra, b) & 0x15ull))
+					t = -1;
+				if (t < 0) { // a letter that is no base: no interval crosses it
+					for (int k = 0; k < 64; k++)
+						tab[k] = 0u;
+					size = rw_pairs = 0;
+					start = b + 1;
+				}
 			}
-			t = (int)(in_w & 63ull);
-			in_w >>= 2;
-			if (ra && (window64(ra, b) & 0x15ull))
-				t = -1;
-			if (t < 0) { // a letter that is no base: no interval crosses it
-				for (int k = 0; k < 32; k++)
-					c32[k] = 0u;
-				size = L = rw_pairs = 0;
-			}
-		}
-		if constexpr (REGS) {
-			// (the leaving triplet's register: every lane whose window is full is at the same position b - 62)
-			if (b >= kDustMaxT && ((b - kDustMaxT) & 15) == 0)
-				out_w = reg_window64(R, b - kDustMaxT);
 		}
 		if (t >= 0) {
-		if (size >= kDustMaxT) {
-			// the oldest triplet leaves: position b - 62 (the window was full, so it is 62 triplets behind)
-			const int ob = b - kDustMaxT;
-			int s0;
-			if constexpr (REGS) {
-				s0 = (int)((out_w >> (2 * (ob & 15))) & 63ull);
-			} else {
-				if (ob != out_pos || (ob & 15) == 0) {
-					out_w = window64(rw, ob);
-					out_pos = ob;
-				}
-				s0 = (int)(out_w & 63ull);
-				out_w >>= 2;
-				out_pos++;
-			}
-			// the leaving and the entering triplet in one go: four counters read together, then written (four dependent
-			// read-modify-writes of LDS bytes per position were the rest of this kernel's time).  Same triplet leaving and
-			// entering: the counts and the pair sum end where they were.
-			const bool in_suffix = L > size - 1;
-			if (s0 != t) {
-				const int cw_s = ld.cw[s0], cv_s = ld.cv[s0], cw_t = ld.cw[t], cv_t = ld.cv[t];
-				ld.cw[s0] = (uint8_t)(cw_s - 1);
-				rw_pairs += cw_t - (cw_s - 1);
-				ld.cw[t] = (uint8_t)(cw_t + 1);
-				if (in_suffix)
-					ld.cv[s0] = (uint8_t)(cv_s - 1);
-				cv_now = cv_t + 1;
-				ld.cv[t] = (uint8_t)cv_now;
-			} else if (in_suffix) {
-				cv_now = ld.cv[t]; // (one out, one in)
-			} else {
-				// the leaving copy lies before the suffix: only the window's count is a wash, the suffix gains one
-				cv_now = ld.cv[t] + 1;
-				ld.cv[t] = (uint8_t)cv_now;
-			}
-			if (!in_suffix)
-				L++; // (size stays: one left, one entered)
-		} else {
-			size++;
-			L++;
-			const int cw_t = ld.cw[t], cv_t = ld.cv[t];
-			rw_pairs += cw_t;
-			ld.cw[t] = (uint8_t)(cw_t + 1);
-			cv_now = cv_t + 1;
-			ld.cv[t] = (uint8_t)cv_now;
-		}
-		}
-		dust_wave_order();
-		// The suffix shrinks past the earliest copy of t when t now occurs more than 4 times in it.  Some lane of the 64 needs
-		// that at most positions, and a lane's own loop over up to 61 triplets (a counter read-modify-write each) held up
-		// the other 63: the WAVEFRONT shrinks one lane's suffix at a time -- lane j looks at the suffix's j-th triplet, a
-		// ballot finds the earliest copy, and every lane up to it takes its triplet out of lane x's counters with ONE LDS
-		// atomic on the counter's word (a byte never borrows: the triplet is in the suffix).  Nothing waits: the LDS
-		// operations of a wavefront execute in the order they were issued, so lane x's next read of its counters sees
-		// them.  (Round 3 went through a 64-bin histogram: five LDS round trips per shrink, ~1 500 cycles per position.)
-		for (unsigned long long need = __ballot(cv_now * 10 > 2 * kDustLevel); need; need &= need - 1ull) {
-			const int x = __ffsll((unsigned long long)need) - 1, lane = (int)(threadIdx.x & 63);
-			const int xL = __builtin_amdgcn_readlane(L, x), xt = __builtin_amdgcn_readlane(t, x), xsp = b - xL + 1;
-			int val = -1;
-			if constexpr (REGS) {
-				// the (at most four) words of lane x's read that hold the suffix, through scalar registers
-				const int w0 = xsp >> 5; // (the same in every lane)
-				uint64_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-#pragma unroll
-				for (int k = 0; k < NW; k++)
-					if (w0 == k) {
-						o0 = readlane64(R[k], x);
-						o1 = readlane64(R[k + 1], x);
-						o2 = readlane64(R[k + 2], x);
-						o3 = readlane64(R[k + 3], x);
+			uint32_t wt = tab[t];
+			int cnt = (int)(wt >> 24); // the entering triplet's count in the window, itself included (below)
+			if (size >= kDustMaxT) {
+				// the oldest triplet leaves: position b - 62 (the window was full, so it is 62 triplets behind)
+				const int ob = b - kDustMaxT;
+				int s0;
+				if constexpr (REGS) {
+					s0 = (int)((out_w >> (2 * (ob & 15))) & 63ull);
+				} else {
+					if (ob != out_pos || (ob & 15) == 0) {
+						out_w = window64(rw, ob);
+						out_pos = ob;
 					}
-				const int p = xsp + lane, wi = (p >> 5) - w0, sh = (p & 31) * 2; // wi = 0, 1 or 2
-				const uint64_t lo = wi == 0 ? o0 : (wi == 1 ? o1 : o2), hi = wi == 0 ? o1 : (wi == 1 ? o2 : o3);
-				const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-				val = lane < xL ? (int)(w & 63ull) : -1;
+					s0 = (int)(out_w & 63ull);
+					out_w >>= 2;
+					out_pos++;
+				}
+				if (s0 != t) {
+					const uint32_t ws = tab[s0];
+					tab[s0] = ws - (1u << 24);
+					rw_pairs += cnt - ((int)(ws >> 24) - 1);
+					cnt++;
+				} // (the same triplet leaving and entering: its count and the pair sum end where they were)
 			} else {
-				const uint64_t *xrw = reinterpret_cast<const uint64_t *>(
-					((unsigned long long)(uint32_t)__shfl((int)((uintptr_t)rw >> 32), x) << 32) | (uint32_t)__shfl((int)(uintptr_t)rw, x));
-				val = lane < xL ? (int)(window64(xrw, xsp + lane) & 63ull) : -1;
+				size++;
+				rw_pairs += cnt;
+				cnt++;
 			}
-			const unsigned long long hit = __ballot(val == xt);
-			const int k = __ffsll((unsigned long long)hit) - 1; // the earliest copy (the entering one is in the suffix: there is one)
-			if (lane <= k)
-				atomicSub(reinterpret_cast<uint32_t *>(s_lane[x].cv) + (val >> 2), 1u << (8 * (val & 3)));
-			if (lane == x)
-				L -= k + 1;
-			dust_wave_order();
-		}
-		if (t >= 0 && rw_pairs * 10 > L * kDustLevel) {
-			first = first < 0 ? b : first;
-			last = b;
+			// its fifth-most-recent occurrence = the oldest of the four positions kept, valid when the window holds five
+			if (cnt >= 5) {
+				const int d = (b - (int)((wt >> 18) & 63u)) & 63; // 4 .. 61 positions back
+				const int cand = b - d + 1;
+				start = cand > start ? cand : start;
+			}
+			tab[t] = (((wt << 6) | (uint32_t)(b & 63)) & 0xFFFFFFu) | ((uint32_t)cnt << 24);
+			int L = b - start + 1;
+			L = L < size ? L : size;
+			if (rw_pairs * 10 > L * kDustLevel) {
+				first = first < 0 ? b : first;
+				last = b;
+			}
 		}
 	}
 	// one atomic per wavefront (a single counter takes ~90 M atomics a second: one per listed read was most of this kernel)
@@ -337,14 +280,22 @@ __global__ __launch_bounds__(64) void k_dust_perfect(const uint64_t *__restrict_
 			uint32_t myP = 0, myN = 0, myQ = 1; // lane l: lane 0's values at length l
 			int end = -1;                       // furthest base a perfect interval of this start covers
 			const int l_max = b_hi - a0 + 1 < kDustMaxT ? b_hi - a0 + 1 : kDustMaxT; // (lane 0's reach; the other lanes die earlier)
+			// (two copies of the loop: without a chunk above -- the only chunk of most reads -- lane 63's neighbour values are
+			// constants, which lets the compiler fold the wave shifts into the instructions that use them)
+			auto steps = [&](auto UP) {
+			constexpr bool HAS_UP = decltype(UP)::value;
+			// (lane 63's constants as opaque registers: as literals the compiler folds the shift into the instruction that
+			// uses it with bound_ctrl, and the results were wrong on gfx950)
+			int k_zero = 0, k_one = 1, k_none = -1;
+			asm volatile("" : "+v"(k_zero), "+v"(k_one), "+v"(k_none));
 			for (int l = 2; l <= l_max; l++) {
 				// lane j + 1's registers before this step: its pairs at l - 1 and l - 2, its best at l - 1, its end triplet;
 				// lane 63's neighbour is lane 0 of the chunk above
-				const uint32_t nP1 = (uint32_t)dust_dpp_up((int)P1, __builtin_amdgcn_readlane((int)upP, l - 1));
-				const uint32_t nP2 = (uint32_t)dust_dpp_up((int)P2, l > 2 ? __builtin_amdgcn_readlane((int)upP, l - 2) : 0);
-				const uint32_t nBn = (uint32_t)dust_dpp_up((int)Bn, __builtin_amdgcn_readlane((int)upN, l - 1));
-				const uint32_t nBq = (uint32_t)dust_dpp_up((int)Bq, __builtin_amdgcn_readlane((int)upQ, l - 1));
-				tb = dust_dpp_up(tb, __builtin_amdgcn_readlane(t_far, l - 2)); // position a0 + 63 + l - 1
+				const uint32_t nP1 = (uint32_t)dust_dpp_up((int)P1, HAS_UP ? __builtin_amdgcn_readlane((int)upP, l - 1) : k_zero);
+				const uint32_t nP2 = (uint32_t)dust_dpp_up((int)P2, HAS_UP && l > 2 ? __builtin_amdgcn_readlane((int)upP, l - 2) : k_zero);
+				const uint32_t nBn = (uint32_t)dust_dpp_up((int)Bn, HAS_UP ? __builtin_amdgcn_readlane((int)upN, l - 1) : k_zero);
+				const uint32_t nBq = (uint32_t)dust_dpp_up((int)Bq, HAS_UP ? __builtin_amdgcn_readlane((int)upQ, l - 1) : k_one);
+				tb = dust_dpp_up(tb, HAS_UP ? __builtin_amdgcn_readlane(t_far, l - 2) : k_none); // position a0 + 63 + l - 1
 				live = live && tb >= 0 && a + l - 1 <= b_hi;
 				const uint32_t P = P1 + nP1 - nP2 + (tb == ta ? 1u : 0u);
 				const uint32_t q = (uint32_t)(l - 1);
@@ -370,6 +321,11 @@ __global__ __launch_bounds__(64) void k_dust_perfect(const uint64_t *__restrict_
 					myQ = me ? q0 : myQ;
 				}
 			}
+			};
+			if (has_up)
+				steps(std::true_type{});
+			else
+				steps(std::false_type{});
 			if (c > 0) {
 				s_up[0][lane] = myP;
 				s_up[1][lane] = myN;
