@@ -232,7 +232,7 @@ static int8_t blast_rank_index(const std::string &t)
 	return (t.size() == 1 && t[0] >= '0' && t[0] <= '6') ? (int8_t)(t[0] - '0') : (int8_t)-1;
 }
 
-static int8_t rdp_rank_index(const std::string &t)
+int8_t rdp_rank_index(const std::string &t)
 {
 	static const char *const r[7] = { "domain", "phylum", "class", "order", "family", "genus", "species" };
 	for (int i = 0; i < 7; i++)
@@ -242,7 +242,7 @@ static int8_t rdp_rank_index(const std::string &t)
 }
 
 // Consensus:159-160: quotes and backslashes, then every [\W\d_] removed: ASCII letters remain
-static std::string clean_rdp_name(const std::string &s)
+std::string clean_rdp_name(const std::string &s)
 {
 	std::string o;
 	for (char c : s)
@@ -733,6 +733,18 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		t_prev = now;
 	};
 	lap("file read");
+	// The import on the device (rdp_device.hip) whenever the batch's names lie in HBM and do not repeat; the host form below
+	// for the rest (synthetic batches, names that repeat, more distinct taxa than the device sets hold) and on request
+	// (PGX_RDP_HOST=1: the two forms are compared by the tests)
+	if (!getenv("PGX_RDP_HOST")) {
+		const int drc = guard("pgx_rdp_from_file", [&]() -> int { return rdp_from_text_device(text.data(), text.size(), reads, db, out); });
+		if (drc <= 0) {
+			if (trace)
+				fprintf(stderr, "[pgx trace] rdp_from_file on the device in all: %.3f s\n",
+					std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+			return drc;
+		}
+	}
 	std::vector<uint32_t> off(n + 1, 0), trips(n ? n : 1, 0);
 	std::vector<uint8_t> present(n ? n : 1, 0);
 	// A line belongs to the first read at or after the cursor that carries its name (the streams are in the same

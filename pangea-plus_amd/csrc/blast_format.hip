@@ -334,10 +334,11 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 		id_blob += db->ids[i];
 		id_off[i + 1] = (uint32_t)id_blob.size();
 	}
-	// read names
+	// read names: the batch's own compact copy in HBM (seqdb.hip); a batch without one (older callers) gets it made here
 	std::string name_blob;
 	std::vector<uint32_t> name_off;
-	if (!reads->synthetic) {
+	const bool dev_names = !reads->synthetic && reads->d_name_at.base != nullptr;
+	if (!reads->synthetic && !dev_names) {
 		name_off.assign((size_t)reads->n + 1, 0);
 		for (int64_t r = 0; r < reads->n; r++) {
 			name_blob.append(reads->h_text->data() + reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
@@ -365,7 +366,7 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	};
 	PGX_TRY(up_bytes(d_id_blob, id_blob));
 	PGX_TRY(up_u32(d_id_off, id_off));
-	if (!reads->synthetic) {
+	if (!reads->synthetic && !dev_names) {
 		PGX_TRY(up_bytes(d_name_blob, name_blob));
 		PGX_TRY(up_u32(d_name_off, name_off));
 	}
@@ -378,8 +379,8 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	v.read_off = h->d_read_off.data();
 	v.read_cnt = h->d_read_cnt.data();
 	v.read_len = reads->d_len.data();
-	v.name_blob = reads->synthetic ? nullptr : d_name_blob.data();
-	v.name_off = d_name_off.data();
+	v.name_blob = reads->synthetic ? nullptr : (dev_names ? reads->d_names.data() : d_name_blob.data());
+	v.name_off = dev_names ? reads->d_name_at.data() : d_name_off.data();
 	v.first = (unsigned long long)reads->first;
 	v.id_blob = d_id_blob.data();
 	v.id_off = d_id_off.data();
@@ -566,7 +567,8 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 			lin_blob += db->lin_text[i];
 			lin_off[i + 1] = (uint32_t)lin_blob.size();
 		}
-		if (!reads->synthetic) {
+		const bool dev_names = !reads->synthetic && reads->d_name_at.base != nullptr;
+		if (!reads->synthetic && !dev_names) {
 			name_off.assign((size_t)n + 1, 0);
 			for (int64_t r = 0; r < n; r++) {
 				name_blob.append(reads->h_text->data() + reads->name_off[(size_t)r], reads->name_len[(size_t)r]);
@@ -586,7 +588,7 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 		};
 		PGX_TRY(up_bytes(d_lin_blob, lin_blob));
 		PGX_TRY(up_u32(d_lin_off, lin_off));
-		if (!reads->synthetic) {
+		if (!reads->synthetic && !dev_names) {
 			PGX_TRY(up_bytes(d_name_blob, name_blob));
 			PGX_TRY(up_u32(d_name_off, name_off));
 		}
@@ -601,8 +603,8 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 		c.f.read_off = hits->d_read_off.data();
 		c.f.read_cnt = hits->d_read_cnt.data();
 		c.f.read_len = reads->d_len.data();
-		c.f.name_blob = reads->synthetic ? nullptr : d_name_blob.data();
-		c.f.name_off = d_name_off.data();
+		c.f.name_blob = reads->synthetic ? nullptr : (dev_names ? reads->d_names.data() : d_name_blob.data());
+		c.f.name_off = dev_names ? reads->d_name_at.data() : d_name_off.data();
 		c.f.first = (unsigned long long)reads->first;
 		c.f.id_blob = d_lin_blob.data();
 		c.f.id_off = d_lin_off.data();

@@ -92,10 +92,13 @@ struct pgx_reads {
 	int64_t first = 0; // ordinal of read 0 within its source (names r<first+i> for synthetic reads)
 	bool synthetic = false;
 	bool has_amb = false;
-	// names of file-built batches: first word of each header, kept as (offset, length) into the file's text
-	std::shared_ptr<const pgx::TextBlob> h_text; // may be shared by several batches cut from one piece of a file
+	// names of file-built batches: first word of each header, the batch's OWN compact copy: (offset, length) into h_text on
+	// the host, d_name_at[i] .. d_name_at[i + 1] into d_names on the device (the formatters and the RDP import use those)
+	std::shared_ptr<const pgx::TextBlob> h_text;
 	std::vector<uint64_t> name_off;
 	std::vector<uint32_t> name_len;
+	pgx::DevBuf<unsigned char> d_names;
+	pgx::DevBuf<uint32_t> d_name_at;
 	std::vector<uint32_t> h_len, h_woff;
 	std::vector<uint8_t> h_read_amb; // per read: holds an ambiguity letter (empty: none does)
 	std::vector<uint8_t> h_read_dust; // per read: holds a DUST-masked base (empty: none does)
@@ -282,6 +285,15 @@ int reads_from_fasta_text(std::shared_ptr<const TextBlob> text, int64_t first, i
 			  std::vector<uint32_t> *amb_count, pgx_reads **out);
 int db_build_index(pgx_db *db);
 int choose_index_bits(int64_t n_postings);
+
+// trim.hip
+int device_line_index(const uint8_t *d_text, uint64_t n, bool open_tail, DevBuf<uint64_t> &start, uint64_t *n_lines_out);
+
+// annotate.hip / rdp_device.hip
+int8_t rdp_rank_index(const std::string &t);
+std::string clean_rdp_name(const std::string &s);
+// the RDP table of a batch parsed on the device; 1 = this form does not apply to the batch (the caller takes the host form)
+int rdp_from_text_device(const char *text, size_t n_bytes, const pgx_reads *reads, pgx_db *db, pgx_rdp **out);
 
 // dust.hip
 int reads_dust(pgx_reads *rd);

@@ -956,9 +956,27 @@ __global__ void k_fa_copy_letters(const unsigned char *__restrict__ text, const 
 
 struct DeviceFasta {
 	DevBuf<unsigned char> d_letters;
-	std::vector<uint32_t> let_off;            // n_rec + 1 letter offsets
-	std::vector<uint32_t> name_off, name_len; // first word of each header, in the host text
+	std::vector<uint32_t> let_off; // n_rec + 1 letter offsets
+	// the names (first word of each header) behind one another, gathered on the device while the text is there: n_rec + 1
+	// offsets and the bytes, on the device and on the host.  The batch keeps THESE, not the file: round 3 kept the file
+	// mapped for the batch's life and read names from it on demand (a file rewritten in place changed them)
+	DevBuf<unsigned char> d_names;
+	DevBuf<uint32_t> d_name_at;
+	std::vector<uint32_t> name_at;
+	std::string names;
 };
+
+// names of the records into one blob: one lane per record (a name is a handful of bytes)
+__global__ void k_fa_gather_names(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_name_off,
+				  const uint32_t *__restrict__ name_at, uint32_t n_rec, unsigned char *__restrict__ names)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_rec)
+		return;
+	const uint32_t a = name_at[r], n = name_at[r + 1] - a, s = rec_name_off[r];
+	for (uint32_t k = 0; k < n; k++)
+		names[a + k] = text[s + k];
+}
 
 static int u32_scan(const uint32_t *in, uint32_t *out, size_t n, bool inclusive)
 {
@@ -1034,12 +1052,23 @@ static int fasta_split_device(const char *text, size_t n_bytes, DeviceFasta &out
 			   d_rnl.data());
 	PGX_HIP(hipGetLastError());
 	out.let_off.resize((size_t)n_rec + 1);
-	out.name_off.resize(n_rec);
-	out.name_len.resize(n_rec);
 	PGX_TRY(d_rlo.download(out.let_off.data(), n_rec));
 	out.let_off[n_rec] = n_let;
-	PGX_TRY(d_rno.download(out.name_off.data(), n_rec));
-	PGX_TRY(d_rnl.download(out.name_len.data(), n_rec));
+	// the names, compact
+	PGX_HIP(hipMemsetAsync(d_rnl.data() + n_rec, 0, sizeof(uint32_t), 0));
+	PGX_TRY(out.d_name_at.alloc((size_t)n_rec + 1));
+	PGX_TRY(u32_scan(d_rnl.data(), out.d_name_at.data(), (size_t)n_rec + 1, false));
+	out.name_at.resize((size_t)n_rec + 1);
+	PGX_TRY(out.d_name_at.download(out.name_at.data(), (size_t)n_rec + 1));
+	const uint32_t n_name_bytes = out.name_at[n_rec];
+	PGX_TRY(out.d_names.alloc(n_name_bytes ? n_name_bytes : 1, 0, 16));
+	if (n_rec)
+		hipLaunchKernelGGL(k_fa_gather_names, dim3((n_rec + 255) / 256), dim3(256), 0, 0, d_text.data(), d_rno.data(), out.d_name_at.data(), n_rec,
+				   out.d_names.data());
+	PGX_HIP(hipGetLastError());
+	out.names.resize(n_name_bytes);
+	if (n_name_bytes)
+		PGX_TRY(out.d_names.download((unsigned char *)&out.names[0], n_name_bytes));
 	return 0;
 }
 
@@ -1281,8 +1310,8 @@ int reads_from_fasta_text(std::shared_ptr<const TextBlob> text_ptr, int64_t firs
 		if ((int32_t)L > rd->max_len)
 			rd->max_len = (int32_t)L;
 		if (on_device) {
-			rd->name_off[(size_t)i] = df.name_off[(size_t)(first + i)];
-			rd->name_len[(size_t)i] = df.name_len[(size_t)(first + i)];
+			rd->name_off[(size_t)i] = df.name_at[(size_t)(first + i)] - df.name_at[(size_t)first];
+			rd->name_len[(size_t)i] = df.name_at[(size_t)(first + i) + 1] - df.name_at[(size_t)(first + i)];
 		} else {
 			const std::string nm = first_word(fl.headers[(size_t)(first + i)]);
 			rd->name_off[(size_t)i] = own_names.size();
@@ -1302,12 +1331,26 @@ int reads_from_fasta_text(std::shared_ptr<const TextBlob> text_ptr, int64_t firs
 	const unsigned char *d_letters_ptr = nullptr;
 	if (on_device) {
 		d_letters_ptr = df.d_letters.data() + l0;
-		rd->h_text = text_ptr; // names are read from the text on demand
+		// the batch's own copy of its names (host and device); the file's text is let go when this call returns
+		const uint32_t nb0 = df.name_at[(size_t)first], nb1 = df.name_at[(size_t)(first + count)];
+		rd->h_text = std::make_shared<const TextBlob>(df.names.substr(nb0, nb1 - nb0));
+		rc = rd->d_names.alloc(nb1 - nb0 ? nb1 - nb0 : 1, 0, 16);
+		if (rc == 0 && nb1 > nb0 && hipMemcpy(rd->d_names.data(), df.d_names.data() + nb0, nb1 - nb0, hipMemcpyDeviceToDevice) != hipSuccess)
+			rc = fail(PGX_E_NODEVICE, "copy of the read names failed");
 	} else {
 		rd->h_text = std::make_shared<const TextBlob>(std::move(own_names));
+		rc = rd->d_names.alloc(rd->h_text->size() ? rd->h_text->size() : 1, 0, 16);
+		if (rc == 0) rc = rd->d_names.upload((const unsigned char *)rd->h_text->data(), rd->h_text->size());
 		rc = d_letters_host.alloc(l1 - l0 ? l1 - l0 : 1, 0, 16);
 		if (rc == 0) rc = d_letters_host.upload((const unsigned char *)fl.letters.data() + l0, l1 - l0);
 		d_letters_ptr = d_letters_host.data();
+	}
+	if (rc == 0) {
+		std::vector<uint32_t> at((size_t)count + 1, 0);
+		for (int64_t i = 0; i < count; i++)
+			at[(size_t)i + 1] = at[(size_t)i] + rd->name_len[(size_t)i];
+		rc = rd->d_name_at.alloc((size_t)count + 1);
+		if (rc == 0) rc = rd->d_name_at.upload(at.data(), at.size());
 	}
 	DevBuf<uint64_t> d_loff;
 	DevBuf<uint32_t> d_namb;

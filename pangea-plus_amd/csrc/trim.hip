@@ -416,6 +416,36 @@ struct StageClock {
 };
 static StageClock g_clock;
 
+// line index of a text that lies in HBM: start[k] = offset of line k, start[n_lines] = behind the last line (the byte after
+// its newline, or the end of a text that does not end in one).  Also the first stage of the RDP import (rdp_device.hip).
+int device_line_index(const uint8_t *d_text, uint64_t n, bool open_tail, DevBuf<uint64_t> &start, uint64_t *n_lines_out)
+{
+	const uint64_t n_tiles = (n + kNlTile - 1) / kNlTile;
+	if (n_tiles >= 0x7FFFFFFFull)
+		return fail(PGX_E_LIMIT, "text of %llu bytes is beyond the line indexer's range", (unsigned long long)n);
+	uint64_t newlines = 0;
+	DevBuf<uint32_t> cnt;
+	DevBuf<uint64_t> off;
+	PGX_TRY(cnt.alloc(n_tiles + 1, 0, 0, true));
+	PGX_TRY(off.alloc(n_tiles + 1, 0, 0, true));
+	if (n_tiles) {
+		hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(kNlThreads), 0, 0, d_text, n, cnt.data(), n_tiles);
+		PGX_HIP(hipGetLastError());
+		PGX_TRY((exclusive_sum<uint32_t, uint64_t>(cnt.data(), off.data(), (size_t)n_tiles + 1)));
+		PGX_TRY(off.download(&newlines, 1, n_tiles));
+	}
+	const uint64_t n_lines = newlines + (open_tail ? 1 : 0);
+	PGX_TRY(start.alloc(newlines + 2, 0, 0, true)); // start[0] = 0
+	if (n_tiles) {
+		hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(kNlThreads), 0, 0, d_text, n, off.data(), start.data());
+		PGX_HIP(hipGetLastError());
+	}
+	if (open_tail)
+		PGX_HIP(hipMemcpy(start.data() + n_lines, &n, sizeof n, hipMemcpyHostToDevice));
+	*n_lines_out = n_lines;
+	return 0;
+}
+
 // the text into HBM and its line index
 static int upload_lines(const std::string &s, DeviceText &d)
 {
@@ -423,29 +453,7 @@ static int upload_lines(const std::string &s, DeviceText &d)
 	PGX_TRY(d.text.alloc(d.n, 0, 16));
 	PGX_TRY(d.text.upload((const uint8_t *)s.data(), d.n));
 	g_clock.tick("upload");
-	const uint64_t n_tiles = (d.n + kNlTile - 1) / kNlTile;
-	if (n_tiles >= 0x7FFFFFFFull)
-		return fail(PGX_E_LIMIT, "read file of %llu bytes is beyond the line indexer's range", (unsigned long long)d.n);
-	uint64_t newlines = 0;
-	DevBuf<uint32_t> cnt;
-	DevBuf<uint64_t> off;
-	PGX_TRY(cnt.alloc(n_tiles + 1, 0, 0, true));
-	PGX_TRY(off.alloc(n_tiles + 1, 0, 0, true));
-	if (n_tiles) {
-		hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_tiles), dim3(kNlThreads), 0, 0, d.text.data(), d.n, cnt.data(), n_tiles);
-		PGX_HIP(hipGetLastError());
-		PGX_TRY((exclusive_sum<uint32_t, uint64_t>(cnt.data(), off.data(), (size_t)n_tiles + 1)));
-		PGX_TRY(off.download(&newlines, 1, n_tiles));
-	}
-	const bool open_tail = d.n > 0 && s[d.n - 1] != '\n';
-	d.n_lines = newlines + (open_tail ? 1 : 0);
-	PGX_TRY(d.start.alloc(newlines + 2, 0, 0, true)); // start[0] = 0
-	if (n_tiles) {
-		hipLaunchKernelGGL(k_nl_write, dim3((unsigned)n_tiles), dim3(kNlThreads), 0, 0, d.text.data(), d.n, off.data(), d.start.data());
-		PGX_HIP(hipGetLastError());
-	}
-	if (open_tail)
-		PGX_HIP(hipMemcpy(d.start.data() + d.n_lines, &d.n, sizeof d.n, hipMemcpyHostToDevice));
+	PGX_TRY(device_line_index(d.text.data(), d.n, d.n > 0 && s[d.n - 1] != '\n', d.start, &d.n_lines));
 	trace_point("trim line index");
 	g_clock.tick("line index");
 	return 0;

@@ -300,6 +300,8 @@ def test_rdp_text_in_odd_shapes_parses_as_the_oracle_reads_it(pg, chain, tmp_pat
                 out += [rid + "\tx\t\t\t\t\t" + rest, r]                   # a tab inside what stands before the five tabs
             elif k == 9 and foreign:
                 out += [rid + "x\t\t\t\t" + rest, r]                       # four tabs only: the whole line is the id
+            elif k == 10 and foreign and i > 40:
+                out += [rows[i - 37].replace("genus", "class"), r]          # a read that lies behind the cursor: its line is skipped
             else:
                 out.append(r)
         return "\n".join(out)                                             # and no newline at the very end
@@ -314,18 +316,27 @@ def test_rdp_text_in_odd_shapes_parses_as_the_oracle_reads_it(pg, chain, tmp_pat
     db = pg.Db.from_synth(cfg)
     db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
     reads = pg.Reads.from_fasta(str(chain / "reads.fa"))
+    # both forms of the import: on the device (rdp_device.hip, the default for a batch made from a file) and on the host
+    # cores (PGX_RDP_HOST=1, with 1, 3 and all threads); the table each makes is also written back as text and compared
+    back = {}
     try:
-        for threads in ("1", "3", None):
-            if threads:
-                os.environ["PGX_RDP_THREADS"] = threads
-            else:
-                os.environ.pop("PGX_RDP_THREADS", None)
+        for threads in ("device", "1", "3", None):
+            os.environ.pop("PGX_RDP_THREADS", None)
+            os.environ.pop("PGX_RDP_HOST", None)
+            if threads != "device":
+                os.environ["PGX_RDP_HOST"] = "1"
+                if threads:
+                    os.environ["PGX_RDP_THREADS"] = threads
             for name in ("odd.tsv", "odd_foreign.tsv"):
                 rdp = pg.Rdp.from_file(str(tmp_path / name), reads, db)
                 hits, recs = _capi.classify_consensus(db, reads, rdp)
                 assert _capi.consensus_format(db, reads, hits, recs) == want, (threads, name)
+                rdp.write_file(str(tmp_path / "back.tsv"), reads, db)
+                back.setdefault(name, (tmp_path / "back.tsv").read_bytes())
+                assert back[name] == (tmp_path / "back.tsv").read_bytes() and len(back[name]) > 10000, (threads, name)
     finally:
         os.environ.pop("PGX_RDP_THREADS", None)
+        os.environ.pop("PGX_RDP_HOST", None)
     # an empty file and a file of newlines: no read has a line
     for name, body in (("empty.tsv", ""), ("newlines.tsv", "\n\n\n")):
         (tmp_path / name).write_text(body)
