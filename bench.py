@@ -246,8 +246,8 @@ def main():
                     "hbm_total_GiB": total_b / 2**30, "broadcast_s": t_bcast, "index_rebuild_s": t_rebuild, "checksum": list(db.checksum())}
             bad = 0
             if world > 1:
-                # checksums as two halves (the sums are 64-bit; the collective is on int64 tensors)
-                cs = torch.tensor([x & 0x7FFFFFFF for x in mine["checksum"]] + [x >> 31 for x in mine["checksum"]], dtype=torch.int64, device=dev)
+                # the 64-bit sums as three non-negative pieces each (bits 0-21, 22-43, 44-63: the collective is on int64 tensors)
+                cs = torch.tensor([(x >> sh) & 0x3FFFFF for x in mine["checksum"] for sh in (0, 22, 44)], dtype=torch.int64, device=dev)
                 rank0 = cs.clone()
                 dist.broadcast(rank0, src=0)
                 bad = int(not torch.equal(cs, rank0))

@@ -82,9 +82,10 @@ int pgx_db_get_shape(const pgx_db *db, pgx_db_shape *out);
 int pgx_db_alloc_like(const pgx_db_shape *shape, pgx_db **out);
 int pgx_db_finish_import(pgx_db *db);
 /* Sums over the database as it stands in THIS GPU's memory, for ranks to compare after the one broadcast of a multi-GPU
- * run (the launcher this stands in for: reference Scripts/submit_MPI-blast.job:24; bench.py --dry-ranks): out[0] = sum of
- * the packed base words, out[1] = sum of the sequence offsets, out[2] = sum of the seed index's bucket offsets, out[3] = sum of
- * its postings -- each a wrapping 64-bit sum of the array's elements, computed on the device. */
+ * run (the launcher this stands in for: reference Scripts/submit_MPI-blast.job:24; bench.py --dry-ranks): out[0] over the
+ * packed base words, out[1] the sequence offsets, out[2] the seed index's bucket offsets, out[3] its postings -- each the
+ * wrapping 64-bit sum of element i times (2 i + 1), computed on the device: elements in other places, or in another order,
+ * give another sum (postings are position-sorted inside a bucket, so every rank's rebuild gives rank 0's order). */
 int pgx_db_checksum(pgx_db *db, uint64_t out[4]);
 
 /* ------------------------------------------------------------------------------------------

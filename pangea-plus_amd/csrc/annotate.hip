@@ -794,7 +794,8 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 		const size_t e = i + 1 < n_lines ? ls[i + 1] - 1 : (text.size() && text.back() == '\n' ? text.size() - 1 : text.size());
 		*len = e - ls[i];
 	};
-	const unsigned hw_env = getenv("PGX_RDP_THREADS") ? (unsigned)atoi(getenv("PGX_RDP_THREADS")) : 0u; // (measurement aid)
+	// (measurement aid; clamped: a negative or huge value used to size the per-thread tables and start that many threads)
+	const unsigned hw_env = getenv("PGX_RDP_THREADS") ? (unsigned)std::max(1, std::min(64, atoi(getenv("PGX_RDP_THREADS")))) : 0u;
 	const unsigned hw = hw_env ? hw_env : (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_lines / 4096 + 1));
 	auto parallel = [&](const std::function<void(unsigned, size_t, size_t)> &f) {
 		std::vector<std::thread> th;
@@ -1044,8 +1045,24 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			std::move(text), std::move(off), std::move(trips), std::move(present), std::move(index.slot), std::move(index.next), std::move(index.hash),
 			std::move(ls), std::move(line_read), std::move(id_len), std::move(has_five), std::move(t_name), std::move(t_rank), std::move(t_local),
 			std::move(tok_of), std::move(name_a), std::move(code_a), std::move(rank_a));
+		// (a joinable thread, waited for by the next import or at exit: a detached one could still be unmapping when the
+		// library is unloaded)
+		static std::mutex junk_mu;
+		static std::thread junk_thread;
+		struct JoinAtExit {
+			~JoinAtExit()
+			{
+				std::lock_guard<std::mutex> lk(junk_mu);
+				if (junk_thread.joinable())
+					junk_thread.join();
+			}
+		};
+		static JoinAtExit join_at_exit;
+		std::lock_guard<std::mutex> lk(junk_mu);
+		if (junk_thread.joinable())
+			junk_thread.join();
 		try {
-			std::thread([j = std::move(junk)]() mutable { j.reset(); }).detach();
+			junk_thread = std::thread([j = std::move(junk)]() mutable { j.reset(); });
 		} catch (...) {
 			// (no thread to be had: freed here)
 		}
@@ -1412,7 +1429,12 @@ int pgx_consensus_format_file(const pgx_db *db, const pgx_reads *reads, const pg
 		return fail(PGX_E_ARG, "pgx_consensus_format_file: database is not bound to a taxonomy");
 	if (n > reads->n)
 		n = reads->n;
-	FILE *f = fopen(path, "wb");
+	// The text goes to a file beside `path` and takes its name when all of it is written: a render that fails no longer leaves
+	// the caller's file truncated.  What is not a regular file (a pipe, /dev/stdout) is written in place.
+	struct stat st;
+	const bool in_place = stat(path, &st) == 0 && !S_ISREG(st.st_mode);
+	const std::string tmp_path = in_place ? std::string(path) : std::string(path) + ".part" + std::to_string((long long)getpid());
+	FILE *f = fopen(tmp_path.c_str(), "wb");
 	if (!f)
 		return fail(PGX_E_IO, "Unable to open %s", path);
 	size_t total = 0;
@@ -1437,6 +1459,14 @@ int pgx_consensus_format_file(const pgx_db *db, const pgx_reads *reads, const pg
 	}
 	if (fclose(f) != 0)
 		io_ok = false;
+	if (!in_place) {
+		if (rc < 0 || !io_ok)
+			unlink(tmp_path.c_str());
+		else if (rename(tmp_path.c_str(), path) != 0) {
+			unlink(tmp_path.c_str());
+			io_ok = false;
+		}
+	}
 	if (rc < 0)
 		return rc;
 	if (!io_ok)

@@ -1770,7 +1770,8 @@ static DbView db_view(const pgx_db *db)
 	v.blk_subj = db->d_blk_subj.data();
 	v.blk_info = db->d_blk_info.data();
 	v.post_ctx = db->d_post_ctx.data();
-	v.amb_blk = db->has_amb && !getenv("PGX_NO_AMB_BLK") ? db->d_amb_blk.data() : nullptr; // (switch: measurement aid)
+	static const bool no_amb_blk = getenv("PGX_NO_AMB_BLK") != nullptr; // (measurement aid, read once per process)
+	v.amb_blk = db->has_amb && !no_amb_blk ? db->d_amb_blk.data() : nullptr;
 	v.bucket_off = db->d_bucket_off.data();
 	v.postings = db->d_postings.data();
 	v.n_seq = (uint32_t)db->n_seq;
@@ -1778,7 +1779,11 @@ static DbView db_view(const pgx_db *db)
 	v.bits = db->index_bits;
 	v.gapped = db->ungapped ? 0 : 1;
 	v.deep_from = gapped_deep_from();
-	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0;
+#ifdef PGX_STAGE_PROBES
+	v.dbg_stop = getenv("PGX_SEED_STOP") ? atoi(getenv("PGX_SEED_STOP")) : 0; // (measurement builds: the kernel truncated after a stage)
+#else
+	v.dbg_stop = 0;
+#endif
 	return v;
 }
 
@@ -1803,7 +1808,11 @@ static ConsView cons_view(const pgx_db *db, const pgx_rdp *rdp)
 {
 	ConsView cv;
 	memset(&cv, 0, sizeof cv);
+#ifdef PGX_STAGE_PROBES
 	cv.dbg = getenv("PGX_SORT_STOP") ? atoi(getenv("PGX_SORT_STOP")) : 0;
+#else
+	cv.dbg = 0;
+#endif
 	if (db && db->bound) {
 		cv.subj_tok_off = db->d_subj_tok_off.data();
 		cv.subj_tok = db->d_subj_tok.data();
@@ -1931,7 +1940,7 @@ static int workspace_of(pgx_db *db, Workspace **out)
 		auto w = std::make_shared<Workspace>();
 		PGX_HIP(hipGetDevice(&w->device));
 		PGX_HIP(hipStreamCreate(&w->stream));
-		PGX_HIP(hipHostMalloc((void **)&w->h_counters, (kNCounters + 2) * sizeof(unsigned long long)));
+		PGX_HIP(hipHostMalloc((void **)&w->h_counters, (kNCounters + 3) * sizeof(unsigned long long)));
 		PGX_TRY(w->ev.init());
 		PGX_TRY(w->counters.alloc(kNCounters, 0, 0, true));
 		db->work = w;
@@ -2144,8 +2153,11 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		// the one wait of the step: counters (+ the gapped stage's list count, + the last read offset = slots used)
 		PGX_HIP(hipMemcpyAsync(h_cnt, ws.counters.data(), kNCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		h_cnt[kNCounters] = 0;
-		if (dv.gapped)
+		h_cnt[kNCounters + 2] = 0;
+		if (dv.gapped) {
 			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters, ws.gapped.big_count.data(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st)); // lists A and B
+			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 2, ws.gapped.big_count.data() + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st)); // ([5]: below)
+		}
 		PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 1, out->d_read_off.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		PGX_HIP(hipStreamSynchronize(st));
 		H_ovf = h_cnt[4];
@@ -2184,7 +2196,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	tm.postings = (int64_t)h_cnt[2];
 	tm.candidates = (int64_t)h_cnt[3];
 	tm.survivors = (int64_t)h_cnt[6];
-	tm.gapped_wide = (int64_t)(uint32_t)h_cnt[kNCounters] + (int64_t)(uint32_t)(h_cnt[kNCounters] >> 32);
+	// HSPs the first tier listed: list A, plus ITS OWN appends to list B (list B's total also holds what the tier behind list A
+	// passed on: an HSP that went A -> B was counted twice); batches with one list: list A is the count
+	tm.gapped_wide = (int64_t)(uint32_t)h_cnt[kNCounters] + (int64_t)(uint32_t)(h_cnt[kNCounters + 2] >> 32);
 	tm.seed_extend_ms = ws.ev.ms(0, 1);
 	tm.gapped_ms = ws.ev.ms(1, 2);
 	tm.group_ms = ws.ev.ms(2, 3);

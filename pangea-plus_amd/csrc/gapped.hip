@@ -9,18 +9,27 @@
 // (S2 = i + j - 6 d).  R(d, k) = furthest i on diagonal k = i - j with d differences; the rules the paper leaves open
 // are stated in DESIGN.md (spec v2) and restated by the checker in oracle/o_gapped.c.
 //
-// Two kernels in four tiers, the same results; each tier lists what it cannot hold for the next:
-//   k_gapped_fast<0|1, MAXL, WAVES, 18>  one LANE per HSP side (reads of <= 512 bases, <= 18 differences per side): loops over
-//                  the difference count d and the diagonal k are shared by the 64 lanes, the row R(d, .) of a lane is 39
-//                  registers updated in place; a cell carries its own statistics (mismatches, gap openings, open-gap
-//                  kind), so there is no traceback.  No X-drop test is due below 19 differences.
-//   k_gapped_fast<2, 512, 2, 40>  the same code over the LIST of those HSPs with rows for 40 differences and the X-drop history
-//   k_gapped_big<62>   one WAVEFRONT per listed HSP, one lane per diagonal (64 at a time), rows double-buffered in LDS, the
-//                  X-drop history, ambiguity flags; rows for 62 differences a side (32 wavefronts per CU)
-//   k_gapped_big<1000> the same with rows for the spec's 1 000 differences (5 wavefronts per CU)
-// Both cut a cell whose score could not pass the best one even if every remaining letter matched.  The cut cannot change
-// the result (a child's bound is below its parent's, so no surviving cell has a cut parent; a cut cell never holds the
-// best score), which is why the sequential kernel, the parallel one (bound taken one step late) and the checker (no
+// Tiers, the same results from each; a tier lists what it cannot hold for the next:
+//   k_gapped_rows<MAXL, WAVES, 18>   the main table of reads of <= 512 bases: one LANE per HSP, both sides in one round of 64
+//                  HSPs (gap_round); the rounds follow the slot list that the counting sorts k_reg_* / k_seg_* make -- by
+//                  database region, inside a region by the seed stage's level estimates -- and are handed out in order from
+//                  one counter, so the wavefronts in flight share about a megabyte of database words (L2).  The lean cell
+//                  (greedy_rows_lean): the row R(d, .) of a lane in registers, letters in transposed LDS rows, one
+//                  `v_max3` per parent choice, 18 differences a side (no X-drop test is due below 19).
+//   k_gapped_rows<512, 2, 40>        reads of 321-512 bases: the same rounds with rows for 40 differences a side, the
+//                  X-drop history in a register ring (greedy_rows_deep)
+//   k_gapped_pool<FLAT, ...>         the overflow table and batches of long reads: a wavefront orders a pool of HSPs by the
+//                  key byte itself, then gap_round
+//   k_gapped_fast<2, MAXL, WAVES, 18> / <2, 512, 2, 40>   the LISTS behind the lean tier: rows with the full statistics in
+//                  the cell (mismatches, gap openings, open-gap kind) for 18, then 40 differences with the X-drop history
+//   k_gapped_diag  one WAVEFRONT per listed HSP, one lane per diagonal, the level in one register per lane, neighbours by
+//                  DPP wave shifts: reads above 512 bases and what the lane-per-HSP tiers pass on
+//   k_gapped_big<62>, <1000>   one wavefront per listed HSP, rows double-buffered in LDS, ambiguity flags: what
+//                  k_gapped_diag hands on (drift beyond its 64 lanes, ambiguity letters, reads above 2 048 bases)
+// (k_gapped_fast<0|1>, round 2's two-pass pools over the tables, is compiled in measurement builds only: PGX_STAGE_PROBES.)
+// Every tier cuts a cell whose score could not pass the best one even if every remaining letter matched.  The cut cannot
+// change the result (a child's bound is below its parent's, so no surviving cell has a cut parent; a cut cell never holds
+// the best score), which is why the sequential kernel, the parallel ones (bound taken one step late) and the checker (no
 // cut at all) agree.
 #include <type_traits>
 #include "bitops.hpp"
@@ -1020,15 +1029,20 @@ __device__ __forceinline__ void neutral_hit(pgx_hit *hp)
 }
 
 // one atomic per call (a single address takes ~90 M atomics a second: one per listed HSP would cost more than the rows)
-__device__ __forceinline__ void list_append(bool fail, pgx_hit *hp, unsigned long long *__restrict__ list, uint32_t *__restrict__ count, uint32_t cap)
+// `also`: a second counter for the same entries (the first tier's own appends to a list that a later tier appends to as well)
+__device__ __forceinline__ void list_append(bool fail, pgx_hit *hp, unsigned long long *__restrict__ list, uint32_t *__restrict__ count, uint32_t cap,
+					    uint32_t *__restrict__ also = nullptr)
 {
 	const unsigned long long m = __ballot(fail);
 	if (m == 0ull)
 		return;
 	const int lane = threadIdx.x & 63, first = __ffsll((unsigned long long)m) - 1;
 	uint32_t base = 0;
-	if (lane == first)
+	if (lane == first) {
 		base = atomicAdd(count, (uint32_t)__popcll(m));
+		if (also)
+			atomicAdd(also, (uint32_t)__popcll(m));
+	}
 	base = __shfl(base, first);
 	if (fail) {
 		const uint32_t w = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1605,6 +1619,7 @@ struct TierLists {
 	unsigned long long *a, *b;
 	uint32_t *a_count, *b_count;
 	uint32_t cap;
+	uint32_t *b_first; // counts the first tier's own appends to list B (the tier behind list A appends there too), or null
 };
 struct Pending {
 	uint32_t na = 0, nb = 0; // table slots waiting in front row 0 (for list A) and front row 1 (for list B), <= 64 each
@@ -1744,13 +1759,13 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL, D> &lds, const GapView &
 	}
 	const bool fail_a = mine && on && worst == 2, fail_b = mine && (!on || worst == 1);
 	lds_sync(); // (the rows' reads are done before the letters are replaced)
-	auto park = [&](bool fail, uint32_t &n, int row, unsigned long long *list, uint32_t *count) {
+	auto park = [&](bool fail, uint32_t &n, int row, unsigned long long *list, uint32_t *count, uint32_t *also) {
 		const unsigned long long fm = __ballot(fail);
 		if (fm == 0ull)
 			return;
 		const uint32_t cnt = (uint32_t)__popcll(fm);
 		if (n + cnt > 64u) { // the row is full: its slots go to the list, one atomic for all of them
-			list_append(lane < (int)n, table + (lane < (int)n ? lds.seq[row * 64 + lane] : 0u), list, count, tl.cap);
+			list_append(lane < (int)n, table + (lane < (int)n ? lds.seq[row * 64 + lane] : 0u), list, count, tl.cap, also);
 			n = 0;
 			lds_sync();
 		}
@@ -1759,8 +1774,8 @@ __device__ __forceinline__ void gap_round(RowsLds<MAXL, D> &lds, const GapView &
 		n += cnt;
 		lds_sync();
 	};
-	park(fail_a, pend.na, 0, tl.a, tl.a_count);
-	park(fail_b, pend.nb, 1, tl.b, tl.b_count);
+	park(fail_a, pend.na, 0, tl.a, tl.a_count, nullptr);
+	park(fail_b, pend.nb, 1, tl.b, tl.b_count, tl.b_first);
 }
 
 template <int MAXL, int D = kGFastD>
@@ -1768,7 +1783,7 @@ __device__ __forceinline__ void gap_flush(RowsLds<MAXL, D> &lds, pgx_hit *__rest
 {
 	const int lane = threadIdx.x & 63;
 	list_append(lane < (int)pend.na, table + (lane < (int)pend.na ? lds.seq[lane] : 0u), tl.a, tl.a_count, tl.cap);
-	list_append(lane < (int)pend.nb, table + (lane < (int)pend.nb ? lds.seq[64 + lane] : 0u), tl.b, tl.b_count, tl.cap);
+	list_append(lane < (int)pend.nb, table + (lane < (int)pend.nb ? lds.seq[64 + lane] : 0u), tl.b, tl.b_count, tl.cap, tl.b_first);
 	pend.na = pend.nb = 0;
 	lds_sync();
 }
@@ -2416,8 +2431,15 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	const uint32_t big_cap = (uint32_t)std::min<unsigned long long>(want, 0xFFFFFFF0ull);
 	PGX_TRY(gw.big_list.ensure(big_cap));
 	PGX_TRY(gw.big_count.ensure(8));
-	const bool binned = !long_reads && getenv("PGX_GAP_POOLS1") == nullptr; // (PGX_GAP_POOLS1=1: the one-pass pools, for comparison)
-	const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;                // (PGX_GAP_POOLS2=1: the two-pass pools, for comparison)
+#ifdef PGX_STAGE_PROBES
+	// measurement builds keep round 3's comparison forms of the main-table tier (read once per process)
+	static const bool pools1_env = getenv("PGX_GAP_POOLS1") != nullptr; // the one-pass pools
+	static const bool pools2 = getenv("PGX_GAP_POOLS2") != nullptr;     // round 2's two-pass pools
+	const bool binned = !long_reads && !pools1_env;
+#else
+	constexpr bool pools2 = false;
+	const bool binned = !long_reads;
+#endif
 	if (binned) {
 		PGX_TRY(gw.items.ensure(hit_cap)); // the main table's slots in (region, bin) order
 		PGX_TRY(gw.items1.ensure(hit_cap + 16)); // (read as 16-byte words / 4-byte words of keys)
@@ -2451,14 +2473,26 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 		hipLaunchKernelGGL(k_seg_scatter, dim3(256 * 8), dim3(256), 0, stream, gw.keys1.data(), gw.items1.data(), gw.bins.data(), gw.items.data());
 	}
 	unsigned long long *listA = gw.big_list.data(), *listB = gw.big_list2.data();
-	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's), [4] E (in A's)
+	uint32_t *cnt = gw.big_count.data(); // [0] list A, [1] B (both checked by the caller), [2] C (in A's buffer), [3] D (in B's), [4] E (in A's), [5] the first tier's own appends to B
 	// (long reads: every HSP goes straight to the wide kernels, which read list A; reads of 321-512 bases: the first tier
 	// holds 40 differences a side with the full statistics, what it cannot finish goes to list A and the wide kernels too)
-	const bool deep = !long_reads && max_len > gapped_deep_from() && getenv("PGX_GAP_NODEEP") == nullptr;
+	static const bool no_deep = getenv("PGX_GAP_NODEEP") != nullptr; // (measurement aid, read once per process)
+	const bool deep = !long_reads && max_len > gapped_deep_from() && !no_deep;
 	const bool one_list = long_reads || deep;
-	const TierLists tl = { listA, one_list ? listA : listB, cnt, one_list ? cnt : cnt + 1, cap };
+	const TierLists tl = { listA, one_list ? listA : listB, cnt, one_list ? cnt : cnt + 1, cap, one_list ? nullptr : cnt + 5 };
 	// staged sequences sized for the batch's longest read (the LDS footprint decides the occupancy).  The lean rows over
 	// the two tables; then the rows with the full statistics over what they listed (list A), which lists for the wider tiers (B)
+#ifdef PGX_STAGE_PROBES
+#define PGX_POOLS2_MAIN(ML, WV)                                                                                                             \
+	hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap, read_start, \
+			   read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap, gw.side_main.data(), dbg, gw.order.data())
+#define PGX_POOLS2_OVF(ML, WV)                                                                                                              \
+	hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap, (const uint32_t *)nullptr, \
+			   (const uint32_t *)nullptr, 0u, ovf_count, listA, cnt, cap, gw.side_ovf.data(), dbg, gw.order.data())
+#else
+#define PGX_POOLS2_MAIN(ML, WV) ((void)0)
+#define PGX_POOLS2_OVF(ML, WV) ((void)0)
+#endif
 #define PGX_GAPPED_LAUNCH(ML, WV, DD)                                                                                                          \
 	do {                                                                                                                                 \
 		v.key = main_key;                                                                                                            \
@@ -2467,17 +2501,13 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 			hipLaunchKernelGGL((k_gapped_rows<ML, (WV > 4 ? 4 : WV), DD>), dim3(256u * 4u * (WV > 4 ? 4 : WV) * 2u), dim3(64), 0, stream, v, main_table, \
 					   gw.items.data(), gw.bins.data(), tl);                                                                  \
 		else if (pools2)                                                                                                             \
-			hipLaunchKernelGGL((k_gapped_fast<0, ML, WV, kGFastD>), dim3(grid_wv ? grid_wv : 1), dim3(64), 0, stream, v, main_table, hit_cap,  \
-					   read_start, read_cnt, n, (const unsigned long long *)nullptr, listA, cnt, cap,  \
-					   gw.side_main.data(), dbg, gw.order.data());                                                                                        \
+			PGX_POOLS2_MAIN(ML, WV);                                                                                                 \
 		else                                                                                                                         \
 			hipLaunchKernelGGL((k_gapped_pool<false, ML, (WV > 4 ? 4 : WV)>), dim3(std::max(1u, std::min<unsigned>(grid, 256u * 4u * (WV > 4 ? 4 : WV) * 2u))), dim3(64), 0, stream, \
 					   v, main_table, hit_cap, read_start, read_cnt, n, (const unsigned long long *)nullptr, tl, gw.order.data()); \
 		v.key = ovf_key;                                                                                                             \
 		if (pools2)                                                                                                                  \
-			hipLaunchKernelGGL((k_gapped_fast<1, ML, WV, kGFastD>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,          \
-					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, listA,                    \
-					   cnt, cap, gw.side_ovf.data(), dbg, gw.order.data());                                                              \
+			PGX_POOLS2_OVF(ML, WV);                                                                                                  \
 		else                                                                                                                         \
 			hipLaunchKernelGGL((k_gapped_pool<true, ML, (WV > 4 ? 4 : WV)>), dim3(256), dim3(64), 0, stream, v, ovf_table, ovf_cap,       \
 					   (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, ovf_count, tl, gw.order.data()); \
@@ -2499,6 +2529,8 @@ int gapped_stage(const DbView &dv, const ReadsView &rv, pgx_hit *main_table, con
 	else
 		PGX_GAPPED_LAUNCH(512, 2, kGFastD);
 #undef PGX_GAPPED_LAUNCH
+#undef PGX_POOLS2_MAIN
+#undef PGX_POOLS2_OVF
 	// the wider tiers, each passing on what it cannot hold: the lane-per-HSP kernel with rows for 40 differences a side
 	// and the X-drop history (reads of <= 512 bases without ambiguity letters: most of what reads of 300-500 bases
 	// list), then one wavefront per HSP with rows for 62 differences, then for the spec's 1 000

@@ -1486,7 +1486,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_wrapping_sum(cons
 {
 	unsigned long long acc = 0;
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-		acc += (unsigned long long)a[i];
+		acc += (unsigned long long)a[i] * (2ull * i + 1ull); // (position-weighted: a permuted array sums differently)
 	for (int sh = 32; sh >= 1; sh >>= 1)
 		acc += __shfl_xor(acc, sh);
 	if ((threadIdx.x & 63) == 0)

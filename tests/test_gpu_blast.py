@@ -737,7 +737,7 @@ def test_reads_of_350_to_500_bases_with_19_to_40_differences_a_side(pg, oracle_b
     rows = want.read_bytes().splitlines()
     assert len(rows) > 5000 and max(int(r.split(b"\t")[4]) for r in rows) >= 38   # mismatches of a row: both sides deep
     assert _blast_text(pg, db, rd, tmp_path, "tier2") == want.read_bytes()
-    assert _capi.stage_times().gapped_wide > 1000   # the first tier listed them
+    assert 1000 < _capi.stage_times().gapped_wide <= len(rows) + 1000   # the first tier listed them, each counted once
 
 
 def test_long_queries_that_overhang_the_first_and_the_last_subject(pg, oracle_bin, tmp_path):

@@ -73,7 +73,9 @@ def test_config1_fused_path_gives_the_reference_consensus(pg, config1):
     assert hashlib.sha256(table).hexdigest() == meta["blast_sha256"]
     assert _capi.consensus_format(db, reads, hits, recs) == open(os.path.join(g, "consensus.txt"), "rb").read()
     # 1 400-base queries: every initial HSP goes through the wide gapped kernels (all but a handful are listed for them)
-    assert _capi.stage_times().gapped_wide >= 0.999 * hits.read_offsets(len(reads))[-1]
+    # (and none is counted twice: the figure is the first tier's own list entries)
+    slots = hits.read_offsets(len(reads))[-1]
+    assert 0.999 * slots <= _capi.stage_times().gapped_wide <= slots
 
 
 # ------------------------------------------------------------------------------------------------ config 2
