@@ -167,6 +167,8 @@ template <bool AMB, int NW> struct DenseMask {
 		return r;
 	}
 	__device__ __forceinline__ static int win_first_ge(const Win &w, int n) { return first_set_ge(w.w, n); }
+	// is position p (inside [lo, hi)) flagged?
+	__device__ __forceinline__ bool flagged(int p) const { return (pick(m, p >> 6) >> (p & 63)) & 1ull; }
 	// flagged positions of [a, b) that lie inside [lo, hi)
 	__device__ __forceinline__ int count_range(int a, int b) const
 	{
@@ -201,6 +203,9 @@ template <bool AMB, int NW> struct DenseMask {
 	}
 	// Cursors over the flags for the X-drop walks: the current 64-flag word is consumed bit by bit
 	// (one count-zeros and one clear per mismatch); a new word is picked only when it runs empty.
+	// (32-bit half words -- count-zeros, single-bit mask and clear are one instruction each there, three to four on 64 bits --
+	// were tried in round 4 and ran SLOWER, 32.9 against 31.8 ms: the register allocation of this kernel decides, not its
+	// instruction count.)
 	struct Fwd {
 		uint64_t w;
 		int wi;
@@ -272,6 +277,7 @@ template <bool AMB> struct LazyMask {
 		hi = d.hi;
 	}
 	__device__ __forceinline__ int count_range(int, int) const { return 15; } // (long reads go to the wide gapped kernel anyway)
+	__device__ __forceinline__ bool flagged(int p) const { return first_ge(p) == p; }
 	__device__ __forceinline__ int first_ge(int pos) const
 	{
 		if (pos >= hi)
@@ -584,16 +590,14 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				nmm++;
 				if (best - cur > kXdrop)
 					break;
-				int p2 = M.bwd_next(cl);
-				int n = k - 1 - p2;
-				if (n > 0) {
-					cur += n;
-					if (cur > best) {
-						best = cur;
-						bl = p2 + 1;
-						mm_best = nmm;
-					}
-				}
+				const int p2 = M.bwd_next(cl);
+				// (selects, not branches: a skipped branch still costs the wavefront its mask bookkeeping, and some lane takes
+				// each of them at most steps -- the walks are a third of this kernel)
+				cur += k - 1 - p2; // the matches between the two flagged positions (0 when they are neighbours)
+				const bool up = cur > best;
+				best = up ? cur : best;
+				bl = up ? p2 + 1 : bl;
+				mm_best = up ? nmm : mm_best;
 				k = p2;
 			}
 			int bestr = 0, br = e - 1, mmr_best = 0;
@@ -606,16 +610,12 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				nmm++;
 				if (bestr - cur > kXdrop)
 					break;
-				int n2 = M.fwd_next(cr);
-				int n = n2 - (k + 1);
-				if (n > 0) {
-					cur += n;
-					if (cur > bestr) {
-						bestr = cur;
-						br = n2 - 1;
-						mmr_best = nmm;
-					}
-				}
+				const int n2 = M.fwd_next(cr);
+				cur += n2 - (k + 1);
+				const bool up = cur > bestr;
+				bestr = up ? cur : bestr;
+				br = up ? n2 - 1 : br;
+				mmr_best = up ? nmm : mmr_best;
 				k = n2;
 			}
 			pgx_hit h;
@@ -642,7 +642,7 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				// extension from the middle costs the least: its work grows with the square of the differences on a side).
 				// What leaves here is a seed record (see pack_seed), not a hit.
 				int q = bl + (br - bl) / 2;
-				while (M.first_ge(q) == q)
+				while (M.flagged(q))
 					q--; // (bl is a match)
 				int anchor = M.last_lt(q) + 1;
 				anchor = anchor > bl ? anchor : bl;
@@ -654,7 +654,8 @@ __device__ __forceinline__ void process_candidate(const DbView &db, const uint64
 				// floor((2 letters of the read on the side - B0) / 5): the work estimate its rounds are ordered by.
 				int b0l = 0, b0r = 0, kl = 14, kr = 14; // (estimates stop at 14: the key byte 0xFF marks a slot without a record)
 				if constexpr (Mask::kHasWindows) {
-					const int ml = M.count_range(bl, anchor), mr = M.count_range(anchor, br + 1);
+					// (the walks counted the HSP's mismatches: the right part's follow from the left part's)
+					const int ml = M.count_range(bl, anchor), mr = (int)h.mismatch - ml;
 					b0l = ml <= 18 ? 2 * (anchor - bl) - 6 * ml : 0;
 					b0r = mr <= 18 ? 2 * (br + 1 - anchor) - 6 * mr : 0;
 					b0l = b0l > 0 && b0l < 2047 ? b0l : 0; // (11 bits in the record; 0 = no bound)
