@@ -9,6 +9,7 @@
 // child status.  At most PGX_MPI_PER_GPU (default 4) children share a device at a time; further ranks wait for a slot
 // (N = 8 on a one-GPU machine runs in two waves, on an 8-GPU node all at once).
 // Extra flags after the four positional arguments are blastn's: -ungapped, -dust no.
+#include <signal.h>
 #include <spawn.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -23,6 +24,10 @@
 #include "pangea_hip.h"
 
 extern char **environ;
+
+// a signal that ends the launcher ends its ranks too (mpirun does the same for the job of Scripts/submit_MPI-blast.job)
+static volatile sig_atomic_t g_stop = 0;
+static void on_signal(int sig) { g_stop = sig; }
 
 static int usage()
 {
@@ -127,15 +132,30 @@ int main(int argc, char **argv)
 	if (const char *e = getenv("PGX_MPI_PER_GPU"))
 		per_gpu = atoi(e) > 0 ? atoi(e) : per_gpu;
 
+	struct sigaction sa;
+	memset(&sa, 0, sizeof sa);
+	sa.sa_handler = on_signal; // (no SA_RESTART: waitpid returns EINTR and the loop below sees g_stop)
+	sigaction(SIGINT, &sa, nullptr);
+	sigaction(SIGTERM, &sa, nullptr);
+	sigaction(SIGHUP, &sa, nullptr);
 	std::vector<pid_t> pid((size_t)N, (pid_t)-1);
 	std::vector<int> status((size_t)N, -1);
 	std::vector<int> busy((size_t)n_dev, 0);
 	auto rank_file = [&](long r) { return std::string(out) + ".rank" + std::to_string(r); };
 	long done = 0, running = 0;
 	int worst = 0;
+	bool stopping = false;
 	while (done < N) {
+		if (g_stop && !stopping) {
+			stopping = true;
+			fprintf(stderr, "mpiblastn: signal %d: ending the ranks\n", (int)g_stop);
+			for (long r = 0; r < N; r++)
+				if (pid[(size_t)r] > 0)
+					kill(pid[(size_t)r], SIGTERM);
+			worst = worst > 128 + (int)g_stop ? worst : 128 + (int)g_stop;
+		}
 		// start every waiting rank whose device has a free slot (rank r always runs on device r mod n_dev)
-		for (long r = 0; r < N; r++) {
+		for (long r = 0; r < N && !stopping; r++) {
 			if (pid[(size_t)r] != -1)
 				continue;
 			const int g = (int)(r % n_dev);

@@ -232,25 +232,6 @@ static int8_t blast_rank_index(const std::string &t)
 	return (t.size() == 1 && t[0] >= '0' && t[0] <= '6') ? (int8_t)(t[0] - '0') : (int8_t)-1;
 }
 
-int8_t rdp_rank_index(const std::string &t)
-{
-	static const char *const r[7] = { "domain", "phylum", "class", "order", "family", "genus", "species" };
-	for (int i = 0; i < 7; i++)
-		if (t == r[i])
-			return (int8_t)i;
-	return -1;
-}
-
-// Consensus:159-160: quotes and backslashes, then every [\W\d_] removed: ASCII letters remain
-std::string clean_rdp_name(const std::string &s)
-{
-	std::string o;
-	for (char c : s)
-		if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))
-			o += c;
-	return o;
-}
-
 // similarity strings -> ranks of their byte order ("" and "0" always present: the start values of
 // $blastsim, Consensus:86-92 and :231)
 static void build_sim_ranks(std::vector<std::string> uniq, std::map<std::string, uint32_t> &rank)
@@ -745,277 +726,22 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 			return drc;
 		}
 	}
-	std::vector<uint32_t> off(n + 1, 0), trips(n ? n : 1, 0);
-	std::vector<uint8_t> present(n ? n : 1, 0);
 	// A line belongs to the first read at or after the cursor that carries its name (the streams are in the same
 	// order; names may repeat).  The reads are indexed by name hash so that a line of a read that is not in this
-	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.
+	// batch (another shard, another piece of the file) costs one probe, not a walk over the batch.  The passes
+	// themselves live in rdp_host.hpp (free of HIP: the build container runs them under the sanitizers).
 	ReadNameIndex index(*reads);
 	lap("name index");
-	static const char kFive[] = "\t\t\t\t\t";
-	const char *base = text.data();
-	// ---- lines (all host cores: each takes a stretch of the text and notes the byte after every newline in it)
-	std::vector<size_t> ls; // start of every line, plus the end of the text
-	{
-		const unsigned tw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), text.size() / (1u << 20) + 1));
-		std::vector<std::vector<size_t>> part(tw);
-		std::vector<std::thread> th;
-		for (unsigned t = 0; t < tw; t++)
-			th.emplace_back([&, t]() {
-				const size_t c0 = text.size() * t / tw, c1 = text.size() * (t + 1) / tw;
-				std::vector<size_t> mine; // (the thread's own vector: see pass 2)
-				mine.reserve((c1 - c0) / 64 + 16);
-				for (size_t s0 = c0; s0 < c1;) {
-					const char *nl = (const char *)memchr(base + s0, '\n', c1 - s0);
-					if (!nl)
-						break;
-					s0 = (size_t)(nl - base) + 1;
-					if (s0 < text.size())
-						mine.push_back(s0);
-				}
-				part[t] = std::move(mine);
-			});
-		for (auto &x : th)
-			x.join();
-		size_t total = text.empty() ? 0 : 1;
-		for (auto &v : part)
-			total += v.size();
-		ls.reserve(total + 1);
-		if (!text.empty())
-			ls.push_back(0);
-		for (auto &v : part)
-			ls.insert(ls.end(), v.begin(), v.end());
-	}
-	const size_t n_lines = ls.size();
-	lap("line starts");
-	ls.push_back(text.size() + (text.empty() || text.back() != '\n' ? 1 : 0)); // (line i ends one byte before the next start)
-	auto line_of = [&](size_t i, const char **line, size_t *len) {
-		*line = base + ls[i];
-		const size_t e = i + 1 < n_lines ? ls[i + 1] - 1 : (text.size() && text.back() == '\n' ? text.size() - 1 : text.size());
-		*len = e - ls[i];
-	};
-	// (measurement aid; clamped: a negative or huge value used to size the per-thread tables and start that many threads)
-	const unsigned hw_env = getenv("PGX_RDP_THREADS") ? (unsigned)std::max(1, std::min(64, atoi(getenv("PGX_RDP_THREADS")))) : 0u;
-	const unsigned hw = hw_env ? hw_env : (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_lines / 4096 + 1));
-	auto parallel = [&](const std::function<void(unsigned, size_t, size_t)> &f) {
-		std::vector<std::thread> th;
-		for (unsigned t = 0; t < hw; t++)
-			th.emplace_back(f, t, n_lines * t / hw, n_lines * (t + 1) / hw);
-		for (auto &x : th)
-			x.join();
-	};
-	// ---- pass 1 (all host cores): the read each line names.  With names that do not repeat inside the batch the cursor
-	// rule "first read at or after the cursor" is "the one read of that name, if it is not behind the cursor": a probe per
-	// line, independent of the others; batches with repeated names keep the sequential walk.
-	std::vector<uint32_t> line_read(n_lines, (uint32_t)n);
-	std::vector<uint32_t> id_len(n_lines, 0);
-	std::vector<uint8_t> has_five(n_lines, 0);
-	parallel([&](unsigned, size_t i0, size_t i1) {
-		for (size_t i = i0; i < i1; i++) {
-			const char *line;
-			size_t len;
-			line_of(i, &line, &len);
-			// (the first run of five tabs: from tab to tab -- the C library's memmem spends most of a 130-byte line setting up)
-			const char *five = nullptr;
-			for (const char *tb = (const char *)memchr(line, '\t', len); tb && (size_t)(tb - line) + 5 <= len;) {
-				size_t run = 1;
-				while (run < 5 && tb[run] == '\t')
-					run++;
-				if (run == 5) {
-					five = tb;
-					break;
-				}
-				tb = (const char *)memchr(tb + run, '\t', len - (size_t)(tb + run - line));
-			}
-			id_len[i] = (uint32_t)(five ? (size_t)(five - line) : len);
-			has_five[i] = five != nullptr;
-			if (index.unique)
-				line_read[i] = (uint32_t)index.find(line, id_len[i], 0);
-		}
-	});
-	lap("pass 1 (reads of the lines)");
-	{
-		size_t cursor = 0;
-		for (size_t i = 0; i < n_lines; i++) {
-			size_t r = line_read[i];
-			if (!index.unique)
-				r = index.find(base + ls[i], id_len[i], cursor);
-			else if (r < cursor)
-				r = n; // its only read lies behind the cursor
-			line_read[i] = (uint32_t)r;
-			if (r < n) {
-				cursor = r + 1;
-				present[r] = 1;
-			}
-		}
-	}
-	// ---- pass 2 (all host cores): the (name, rank, confidence) fields of the lines that belong to a read.  The few
-	// distinct name / rank texts of an RDP file are cleaned and interned once each (per thread; the database's token table
-	// behind a lock)
-	lap("cursor rule");
-	// per-thread memo of the distinct field texts (a few thousand per file): open addressing on the text's hash, the text
-	// itself compared on a hit; a full table (never seen) just stops remembering
-	struct Memo {
-		struct Slot {
-			uint64_t h = 0;
-			const char *p = nullptr;
-			uint32_t len = 0, value = 0;
-		};
-		std::vector<Slot> slot;
-		size_t used = 0;
-		explicit Memo(size_t slots) : slot(slots) {}
-		// the slot of the text: *hit says whether it already holds a value.  The table starts small (an RDP file names a few
-		// thousand distinct taxa: 96 KB stay in the core's cache -- the fixed 6 MB table of round 2 missed on every field, 0.28 s
-		// of the 0.56 s a 2 M-line file took) and grows fourfold when half full, up to 2^20 slots
-		Slot *find(const char *p, size_t len, bool *hit) { return find_h(p, len, fnv64_bytes(p, len), hit); }
-		Slot *find_h(const char *p, size_t len, uint64_t hash, bool *hit) // hash = fnv64_bytes(p, len)
-		{
-			const uint64_t h = hash | 1ull; // 0 marks an empty slot
-			for (;;) {
-				size_t k = (size_t)(h >> 8) & (slot.size() - 1);
-				for (;;) {
-					Slot &e = slot[k];
-					if (e.h == h && e.len == len && memcmp(e.p, p, len) == 0) {
-						*hit = true;
-						return &e;
-					}
-					if (e.h == 0)
-						break;
-					k = (k + 1) & (slot.size() - 1);
-				}
-				*hit = false;
-				if (2 * (used + 1) > slot.size()) {
-					if (slot.size() >= (1u << 20))
-						return nullptr;
-					std::vector<Slot> old(slot.size() * 4);
-					old.swap(slot);
-					for (const Slot &o : old) {
-						if (!o.h)
-							continue;
-						size_t j = (size_t)(o.h >> 8) & (slot.size() - 1);
-						while (slot[j].h)
-							j = (j + 1) & (slot.size() - 1);
-						slot[j] = o;
-					}
-					continue; // (probe the grown table)
-				}
-				Slot &e = slot[k];
-				e.h = h;
-				e.p = p; // (the file's text outlives the memo)
-				e.len = (uint32_t)len;
-				used++;
-				return &e;
-			}
-		}
-	};
-	// (the database's token table is touched after the parallel part, once per distinct cleaned name of a thread: with the
-	// table behind a lock, the first sight of 40 000 names in each of 16 threads cost 0.3 s of a 0.6 s pass)
-	std::vector<std::vector<uint32_t>> t_name(hw);
-	std::vector<std::vector<int8_t>> t_rank(hw);
-	std::vector<std::vector<std::string>> t_local(hw); // per thread: its distinct cleaned names, by local number
-	parallel([&](unsigned t, size_t i0, size_t i1) {
-		std::unordered_map<std::string, uint32_t> lmap;
-		std::vector<std::string> loc;
-		// (names: a database with 33 000 genera filled a 65 536-slot table half way, after which every field took the
-		// interning lock: 0.9 s instead of 0.5 s for 2 M lines)
-		Memo names(1 << 12), ranks(1 << 8);
-		// (the thread's OWN vectors, moved into t_name / t_rank / t_local at the end: the headers of those sixteen vectors lie
-		// side by side in memory, and every push_back through a reference to one of them wrote its end pointer into a cache
-		// line that two other threads were writing theirs to -- this pass took 0.27 s on one thread, 0.60 s on four and
-		// 0.28 s on sixteen)
-		std::vector<uint32_t> nm;
-		std::vector<int8_t> rk;
-		nm.reserve((i1 - i0) * 8 + 64);
-		rk.reserve((i1 - i0) * 8 + 64);
-		for (size_t i = i0; i < i1; i++) {
-			const size_t r = line_read[i];
-			if (r >= n || !has_five[i])
-				continue;
-			const char *line;
-			size_t len;
-			line_of(i, &line, &len);
-			const char *rest = line + id_len[i] + 5;
-			size_t rest_len = len - id_len[i] - 5;
-			// (a second five-tab group ends the fields, as before; then ONE walk over the bytes: a field ends at a tab and its
-			// FNV hash is made on the way -- a memchr and a separate hash pass per field were most of this pass)
-			if (const char *again = (const char *)memmem(rest, rest_len, kFive, 5))
-				rest_len = (size_t)(again - rest);
-			while (rest_len && rest[rest_len - 1] == '\t') // trailing empty fields are dropped
-				rest_len--;
-			if (rest_len == 0)
-				continue;
-			size_t a = 0; // start of the current field
-			uint64_t fh = 1469598103934665603ull;
-			int k = 0;
-			for (size_t x = 0; x <= rest_len; x++) {
-				if (x < rest_len && rest[x] != '\t') {
-					fh = (fh ^ (unsigned char)rest[x]) * 1099511628211ull;
-					continue;
-				}
-				// field k = rest[a, x)
-				if (k % 3 == 0) {
-					bool hit;
-					Memo::Slot *e = names.find_h(rest + a, x - a, fh, &hit);
-					uint32_t tok = hit ? e->value : 0u;
-					if (!hit) {
-						const std::string clean = clean_rdp_name(std::string(rest + a, x - a));
-						auto it = lmap.find(clean);
-						if (it == lmap.end()) {
-							it = lmap.emplace(clean, (uint32_t)loc.size()).first;
-							loc.push_back(clean);
-						}
-						tok = it->second; // the thread's own number of the name; token ids follow below
-						if (e)
-							e->value = tok;
-					}
-					nm.push_back(tok);
-					rk.push_back((int8_t)-1);
-					trips[r]++; // (one line per read: no two threads touch one counter)
-				} else if (k % 3 == 1) {
-					bool hit;
-					Memo::Slot *e = ranks.find_h(rest + a, x - a, fh, &hit);
-					uint32_t rv = hit ? e->value : (uint32_t)(uint8_t)rdp_rank_index(std::string(rest + a, x - a));
-					if (!hit && e)
-						e->value = rv;
-					rk.back() = (int8_t)rv;
-				}
-				k++;
-				a = x + 1;
-				fh = 1469598103934665603ull;
-			}
-		}
-		t_name[t] = std::move(nm);
-		t_rank[t] = std::move(rk);
-		t_local[t] = std::move(loc);
-	});
-	lap("pass 2 (fields)");
-	// the threads' pieces behind one another (matched reads come in increasing order, so the triplets already lie in read
-	// order): token ids for each thread's distinct names (the database's table, one thread), then every thread maps and
-	// copies its own piece into arrays that nobody zero-filled first
-	std::vector<std::vector<uint32_t>> tok_of(hw);
-	std::vector<size_t> piece_at(hw + 1, 0);
-	for (unsigned t = 0; t < hw; t++) {
-		tok_of[t].resize(t_local[t].size());
-		for (size_t k = 0; k < tok_of[t].size(); k++)
-			tok_of[t][k] = db->intern(t_local[t][k]);
-		piece_at[t + 1] = piece_at[t] + t_name[t].size();
-	}
-	const size_t n_trip = piece_at[hw];
-	std::unique_ptr<uint32_t[]> name_a(new uint32_t[n_trip + 1]), code_a(new uint32_t[n_trip + 1]);
-	std::unique_ptr<int8_t[]> rank_a(new int8_t[n_trip + 1]);
-	parallel([&](unsigned t, size_t, size_t) {
-		uint32_t *nm = name_a.get() + piece_at[t], *cd = code_a.get() + piece_at[t];
-		int8_t *rk = rank_a.get() + piece_at[t];
-		const std::vector<uint32_t> &src = t_name[t], &map = tok_of[t];
-		const std::vector<int8_t> &srk = t_rank[t];
-		for (size_t k = 0; k < src.size(); k++) {
-			const uint32_t tk = map[src[k]];
-			nm[k] = tk;
-			rk[k] = srk[k];
-			cd[k] = (tk << 3) | (uint32_t)(srk[k] + 1);
-		}
-	});
-	lap("concatenate");
+	int thr = getenv("PGX_RDP_THREADS") ? atoi(getenv("PGX_RDP_THREADS")) : 0; // (measurement aid; clamped: ADVICE r3)
+	thr = thr < 0 ? 1 : (thr > 64 ? 64 : thr);
+	RdpHostTable ht;
+	rdp_parse_host(TextRef{ text.data(), text.size() }, n, index, (unsigned)thr, [&](const std::string &nm) { return db->intern(nm); }, lap, ht);
+	std::vector<uint32_t> off(n + 1, 0);
+	std::vector<uint32_t> &trips = ht.trips;
+	std::vector<uint8_t> &present = ht.present;
+	const size_t n_trip = ht.n_trip;
+	std::unique_ptr<uint32_t[]> &name_a = ht.name_a, &code_a = ht.code_a;
+	std::unique_ptr<int8_t[]> &rank_a = ht.rank_a;
 	pgx_rdp *rd = new pgx_rdp();
 	rd->n = (int64_t)n;
 	rd->max_trip = 0;
@@ -1037,14 +763,8 @@ int pgx_rdp_from_file(const char *path, const pgx_reads *reads, const pgx_db *cd
 	// ~300 MB of work arrays and the file's mapping: unmapping them took 0.02 s of this call's 0.115 s; a thread of its own
 	// does it while the caller goes on
 	{
-		auto junk = std::make_shared<std::tuple<FileText, std::vector<uint32_t>, std::vector<uint32_t>, std::vector<uint8_t>, std::vector<uint32_t>,
-							std::vector<uint32_t>, std::vector<uint64_t>, std::vector<size_t>, std::vector<uint32_t>, std::vector<uint32_t>,
-							std::vector<uint8_t>, std::vector<std::vector<uint32_t>>, std::vector<std::vector<int8_t>>,
-							std::vector<std::vector<std::string>>, std::vector<std::vector<uint32_t>>, std::unique_ptr<uint32_t[]>,
-							std::unique_ptr<uint32_t[]>, std::unique_ptr<int8_t[]>>>(
-			std::move(text), std::move(off), std::move(trips), std::move(present), std::move(index.slot), std::move(index.next), std::move(index.hash),
-			std::move(ls), std::move(line_read), std::move(id_len), std::move(has_five), std::move(t_name), std::move(t_rank), std::move(t_local),
-			std::move(tok_of), std::move(name_a), std::move(code_a), std::move(rank_a));
+		auto junk = std::make_shared<std::tuple<FileText, std::vector<uint32_t>, RdpHostTable, std::vector<uint32_t>, std::vector<uint32_t>, std::vector<uint64_t>>>(
+			std::move(text), std::move(off), std::move(ht), std::move(index.slot), std::move(index.next), std::move(index.hash));
 		// (a joinable thread, waited for by the next import or at exit: a detached one could still be unmapping when the
 		// library is unloaded)
 		static std::mutex junk_mu;

@@ -980,6 +980,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 							keep[u] = false;
 					}
 				}
+				if (PGX_DBG_STOP(db) == 8) { // (measurement builds: postings fetched and filtered, no block record yet)
+					for (int u = 0; u < kDeal; u++)
+						n_runs += keep[u];
+					continue;
+				}
 				// stage 4: subject and bounds of the survivors: the block's first subject, or (a boundary inside
 				// the block) the next one; only blocks holding three or more subjects walk seq_off
 				uint4 bi[kDeal];
@@ -1001,6 +1006,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, NW == 8 ? 3 : 4) void k_seed_e
 							s1[u] = db.seq_off[sj[u] + 1];
 						}
 					}
+				}
+				if (PGX_DBG_STOP(db) == 9) { // (measurement builds: block records fetched, no ownership set yet)
+					for (int u = 0; u < kDeal; u++)
+						n_runs += keep[u] + s1[u];
+					continue;
 				}
 				// stage 5 (two short reads per wave): one candidate per diagonal.  The first survivor of a
 				// (read, strand, diagonal) enters the set and will take ALL exact runs of the diagonal from its

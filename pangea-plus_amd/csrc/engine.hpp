@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "rdp_host.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // Sequence database in HBM.
@@ -154,90 +155,13 @@ struct pgx_rdp {
 
 namespace pgx {
 
-inline uint64_t fnv64_bytes(const char *p, size_t n)
-{
-	uint64_t h = 1469598103934665603ull;
-	for (size_t i = 0; i < n; i++)
-		h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
-	return h;
-}
+// (fnv64_bytes, NameIndexT, the host form of the RDP import: rdp_host.hpp, free of HIP)
 
-// Reads of a batch by name: open-addressing table of name hashes, reads with one hash chained in ascending order.
-// find() = the first read at or after `from` whose name is the given text, or n when there is none.
-struct ReadNameIndex {
+// the names of a batch for NameIndexT
+struct ReadsNames {
 	const pgx_reads &rd;
-	std::vector<uint32_t> slot, next; // slot: first read of a hash (+1, 0 = empty); next: following read of the same hash (+1)
-	std::vector<uint64_t> hash;
-	uint64_t mask = 0;
-	bool unique = true; // no two reads share a name
-	explicit ReadNameIndex(const pgx_reads &r) : rd(r)
-	{
-		const size_t n = (size_t)rd.n;
-		size_t cap = 16;
-		while (cap < 2 * n + 1)
-			cap <<= 1;
-		mask = cap - 1;
-		slot.assign(cap, 0);
-		next.assign(n, 0);
-		hash.resize(n);
-		// All host cores (a 2 M-read batch took 0.08 s on one): the hashes, then the table by compare-and-swap on its slots.
-		// Names that do not repeat need no `next` chain, and any insertion order serves find(); the first repeated name
-		// (or two names with one 64-bit hash) ends the parallel build and the table is made again in read order.
-		const unsigned hw = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1));
-		auto parallel = [&](const std::function<void(size_t, size_t)> &f) {
-			std::vector<std::thread> th;
-			for (unsigned t = 0; t < hw; t++)
-				th.emplace_back(f, n * t / hw, n * (t + 1) / hw);
-			for (auto &x : th)
-				x.join();
-		};
-		parallel([&](size_t i0, size_t i1) {
-			std::string tmp;
-			for (size_t i = i0; i < i1; i++) {
-				const char *p;
-				size_t len;
-				name_span(i, tmp, &p, &len);
-				hash[i] = fnv64_bytes(p, len);
-			}
-		});
-		std::atomic<bool> repeated(false);
-		uint32_t *slots = slot.data();
-		parallel([&](size_t i0, size_t i1) {
-			for (size_t i = i0; i < i1 && !repeated.load(std::memory_order_relaxed); i++) {
-				const uint64_t h = hash[i];
-				size_t k = (size_t)(h & mask);
-				for (;;) {
-					uint32_t cur = __atomic_load_n(&slots[k], __ATOMIC_RELAXED);
-					if (cur == 0) {
-						if (__atomic_compare_exchange_n(&slots[k], &cur, (uint32_t)i + 1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
-							break;
-					}
-					if (hash[cur - 1] == h) {
-						repeated.store(true, std::memory_order_relaxed);
-						break;
-					}
-					k = (k + 1) & mask;
-				}
-			}
-		});
-		if (!repeated.load())
-			return;
-		unique = false;
-		slot.assign(cap, 0);
-		std::vector<uint32_t> last(cap, 0);
-		for (size_t i = 0; i < n; i++) {
-			const uint64_t h = hash[i];
-			size_t k = (size_t)(h & mask);
-			while (slot[k] && hash[slot[k] - 1] != h)
-				k = (k + 1) & mask;
-			if (!slot[k])
-				slot[k] = (uint32_t)i + 1;
-			else
-				next[last[k] - 1] = (uint32_t)i + 1;
-			last[k] = (uint32_t)i + 1;
-		}
-	}
-	void name_span(size_t i, std::string &tmp, const char **p, size_t *len) const
+	size_t size() const { return (size_t)rd.n; }
+	void span(size_t i, std::string &tmp, const char **p, size_t *len) const
 	{
 		if (rd.synthetic) {
 			tmp = rd.name_of((int64_t)i);
@@ -248,27 +172,9 @@ struct ReadNameIndex {
 			*len = rd.name_len[i];
 		}
 	}
-	size_t find(const char *text, size_t len, size_t from) const
-	{
-		const size_t n = (size_t)rd.n;
-		if (n == 0)
-			return n;
-		const uint64_t h = fnv64_bytes(text, len);
-		size_t k = (size_t)(h & mask);
-		while (slot[k] && hash[slot[k] - 1] != h)
-			k = (k + 1) & mask;
-		std::string tmp;
-		for (uint32_t i = slot[k]; i; i = next[i - 1]) {
-			if ((size_t)(i - 1) < from)
-				continue;
-			const char *p;
-			size_t l;
-			name_span(i - 1, tmp, &p, &l);
-			if (l == len && memcmp(p, text, len) == 0)
-				return i - 1;
-		}
-		return n;
-	}
+};
+struct ReadNameIndex : private ReadsNames, public NameIndexT<ReadsNames> {
+	explicit ReadNameIndex(const pgx_reads &r) : ReadsNames{ r }, NameIndexT<ReadsNames>(static_cast<const ReadsNames &>(*this)) {}
 };
 
 // seqdb.hip
@@ -290,8 +196,6 @@ int choose_index_bits(int64_t n_postings);
 int device_line_index(const uint8_t *d_text, uint64_t n, bool open_tail, DevBuf<uint64_t> &start, uint64_t *n_lines_out);
 
 // annotate.hip / rdp_device.hip
-int8_t rdp_rank_index(const std::string &t);
-std::string clean_rdp_name(const std::string &s);
 // the RDP table of a batch parsed on the device; 1 = this form does not apply to the batch (the caller takes the host form)
 int rdp_from_text_device(const char *text, size_t n_bytes, const pgx_reads *reads, pgx_db *db, pgx_rdp **out);
 

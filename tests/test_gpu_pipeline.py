@@ -343,3 +343,67 @@ def test_rdp_text_in_odd_shapes_parses_as_the_oracle_reads_it(pg, chain, tmp_pat
         rdp = pg.Rdp.from_file(str(tmp_path / name), reads, db)
         hits, recs = _capi.classify_consensus(db, reads, rdp)
         assert (recs["hit"] == -2).all()
+
+
+def test_rdp_import_on_the_device_and_on_the_host_agree_on_awkward_files(pg, chain, tmp_path):
+    """The two forms of the RDP import (rdp_device.hip; the host cores, PGX_RDP_HOST=1) on files neither was written for:
+    CRLF line ends, lines in reverse order (only the first survives the cursor rule), every line twice, a 20 KB id, lines that
+    are five tabs and nothing else, names with quotes, digits and high bytes, a name field that is empty, fields behind a
+    second five-tab group, and a batch in which two reads share a name (the device form hands such a batch to the host
+    form).  The tables are compared as the text `pgx_rdp_write_file` makes of them and through the consensus records."""
+    from pangea_plus_amd import _capi
+    rows = (chain / "rdp.tsv").read_text().splitlines()[:1200]
+    cfg = pg.SynthCfg.default(**SHAPE)
+    db = pg.Db.from_synth(cfg)
+    db.bind_taxonomy(pg.TaxDb.open(str(chain / "Tax_class")))
+    reads = pg.Reads.from_fasta(str(chain / "reads.fa"))
+    files = {}
+    files["crlf"] = "\r\n".join(rows) + "\r\n"
+    files["reverse"] = "\n".join(reversed(rows)) + "\n"
+    files["twice"] = "\n".join(r for row in rows for r in (row, row)) + "\n"
+    files["long_id"] = "x" * 20000 + "\t\t\t\t\tBacteria\tdomain\t1.0\n" + "\n".join(rows[:50]) + "\n" + "y" * 70000
+    files["bare_tabs"] = "\t\t\t\t\t\n".join(rows[:300]) + "\n\t\t\t\t\t"
+    odd = []
+    for i, row in enumerate(rows[:600]):
+        rid, rest = row.split("\t\t\t\t\t", 1)
+        f = rest.split("\t")
+        if i % 5 == 0:
+            f[0] = '"' + f[0] + '" 16S_7'
+        elif i % 5 == 1:
+            f[0] = ""
+        elif i % 5 == 2:
+            f[3] = f[3] + "\xe9\xff"
+        elif i % 5 == 3:
+            f = f[:5]
+        odd.append(rid + "\t\t\t\t\t" + "\t".join(f) + ("\t\t\t\t\tignored\tgenus\t0.1" if i % 7 == 0 else ""))
+    files["odd_names"] = "\n".join(odd)
+    for name, body in files.items():
+        (tmp_path / (name + ".tsv")).write_bytes(body.encode("latin-1"))
+    hits = _capi.blast_search(db, reads)
+
+    def both(name, rd):
+        out = []
+        for form in ("device", "host"):
+            os.environ.pop("PGX_RDP_HOST", None)
+            if form == "host":
+                os.environ["PGX_RDP_HOST"] = "1"
+            try:
+                rdp = pg.Rdp.from_file(str(tmp_path / (name + ".tsv")), rd, db)
+            finally:
+                os.environ.pop("PGX_RDP_HOST", None)
+            rdp.write_file(str(tmp_path / "back.tsv"), rd, db)
+            h2, recs = _capi.classify_consensus(db, rd, rdp)
+            out.append(((tmp_path / "back.tsv").read_bytes(), recs.tobytes()))
+        assert out[0] == out[1], name
+        return out[0][0]
+    texts = {name: both(name, reads) for name in files}
+    assert texts["twice"] == texts["crlf"].replace(b"\r", b"") or len(texts["twice"]) > 1000
+    assert texts["reverse"].count(b"\n") <= 2          # the cursor passes every read but the last one named first
+    assert texts["bare_tabs"].count(b"\n") >= 300
+    # two reads with one name: the batch goes to the host form, whichever form was asked for
+    fa = (chain / "reads.fa").read_text().split(">")[1:1201]
+    fa[7] = fa[3].split("\n", 1)[0] + "\n" + fa[7].split("\n", 1)[1]
+    (tmp_path / "dup.fa").write_text("".join(">" + x for x in fa))
+    dup = pg.Reads.from_fasta(str(tmp_path / "dup.fa"))
+    (tmp_path / "dup.tsv").write_text("\n".join(rows) + "\n")
+    assert both("dup", dup).count(b"\n") > 1000

@@ -8,7 +8,7 @@ cfg = pg.SynthCfg.default()
 db = pg.Db.from_synth(cfg)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 reads = pg.Reads.from_synth(cfg, 0, n)
-for stop in ("1", "2", "3", "4", "5", "6", "7", "0"):
+for stop in ("1", "8", "9", "2", "3", "4", "5", "6", "7", "0"):
     os.environ["PGX_SEED_STOP"] = stop
     t = []
     for _ in range(3):
