@@ -1,7 +1,7 @@
-# Round-3 profile: the bench line, rocprofv3 kernel stats of the same command, PMC passes (one counter group per run,
+# Round profile (rounds 3 and 4): the bench line, rocprofv3 kernel stats of the same command, PMC passes (one counter group per run,
 # never combined with tracing) at the bench's own scale (10 M reads: the region order of the gapped stage depends on it).
-# usage: bash tools/round3_profile.sh [tag]   -> gpurun_out/<tag>_profile/
-TAG=${1:-r03}
+# usage: bash tools/round4_profile.sh [tag]   -> gpurun_out/<tag>_profile/
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${TAG}_profile
 mkdir -p $O

@@ -1,4 +1,4 @@
-"""Turn gpurun_out/<tag>_profile/ (tools/round3_profile.sh) into the files under profiles/: kernel stats csv, the PMC sums as
+"""Turn gpurun_out/<tag>_profile/ (tools/round4_profile.sh) into the files under profiles/: kernel stats csv, the PMC sums as
 text, and profiles/traffic.json (per-launch HBM bytes, L2 requests / misses and vector instructions per read for the kernels
 bench.py quotes).  usage: python tools/summarise_profile.py <tag> <round-label> [reads-per-launch]"""
 import ast, csv, json, os, shutil, sys
@@ -37,13 +37,13 @@ def kernel(prefix):
 k = {n: kernel(p) for n, p in (("k_gapped_rows", "k_gapped_rows<160"), ("k_seed_extend", "k_seed_extend<false, 3, true, false>"),
                                ("k_sort_consensus_32", "k_sort_consensus<32>"), ("k_sort_consensus_64", "k_sort_consensus<64>"),
                                ("k_reg_scatter", "k_reg_scatter"), ("k_seg_scatter", "k_seg_scatter"), ("k_reg_hist", "k_reg_hist"), ("k_seg_hist", "k_seg_hist"),
-                               ("k_dust_trigger_false", "k_dust_trigger<false>"), ("k_dust_trigger_true", "k_dust_trigger<true>"), ("k_dust_mask", "k_dust_mask"))}
+                               ("k_dust_scan", "k_dust_scan"), ("k_dust_perfect", "k_dust_perfect"), ("k_dust_windows", "k_dust_windows"))}
 bench = json.load(open(os.path.join(src, "bench.json")))
 gap_ms = bench["stages_ms_last_step"]["gapped"]
 stage_kernels = ("k_gapped_rows", "k_reg_scatter", "k_seg_scatter", "k_reg_hist", "k_seg_hist")
 tj = {
     "round": label,
-    "how": "tools/round3_profile.sh + tools/summarise_profile.py: rocprofv3 --kernel-trace --stats on bench.py --steps 5 --warmup 1, and six rocprofv3 --pmc passes "
+    "how": "tools/round4_profile.sh + tools/summarise_profile.py: rocprofv3 --kernel-trace --stats on bench.py --steps 5 --warmup 1, and six rocprofv3 --pmc passes "
            "(one counter group each, never with tracing) on tools/quick_bench.py 10000000 2, i.e. at the bench's own 10 M reads per launch (the region order of "
            "the gapped stage depends on the launch size); values = mean per dispatch.  FETCH_SIZE / WRITE_SIZE are quoted as counted (KB x 1024): the gfx950 "
            "correction of the guide is calibrated for wide coalesced streams, these kernels move 16-64-byte gathers.",
