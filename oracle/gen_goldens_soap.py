@@ -150,3 +150,106 @@ def generate(scratch, gold, soap_dir, ref_root="/root/reference"):
             shutil.copyfileobj(a, b)
     rows = sum(1 for _ in open(os.path.join(out, "out_r2.txt")))
     print(f"soap: {len(reads)} reads, {rows} rows (-r 2)")
+
+
+def generate_pe(scratch, gold, soap_dir):
+    """Paired-end goldens (soap.man:29-50: -b, -2, -m, -x), produced by the reference's closed ELF against the reference of
+    the single-end goldens (tests/golden/soap/ref.fa).  Pairs are cut from its sequences: inserts around the [-m, -x]
+    boundaries, mates of unequal length (the ELF measures the insert with the A mate's length), 0-3 planted mismatches
+    per mate, A on either strand, same-strand and outward pairs (never paired), a mate that maps nowhere, a mate with more
+    than -n N's, mates of 27-120 bases with two mismatches at swept offsets (the order of the two entries of a row; the
+    ELF's blind spot at 32 bases).  Mates under 27 bases are left out: the ELF crashes on some of them.
+    Outputs (tests/golden/soap/): pe_a.fa, pe_b.fa, pe_{paired,unpaired,unmapped}_r{2,0}.txt[.gz] (-m 400 -x 600) and, for the
+    length sweep, pe_sweep_{a,b}.fa + pe_sweep_{paired,unpaired,unmapped}.txt.gz (-m 300 -x 700 -r 2).
+    usage: python3 oracle/gen_goldens_soap.py pe"""
+    import gzip
+    out = os.path.join(gold, "soap")
+    work = os.path.join(scratch, "soap_pe")
+    os.makedirs(work, exist_ok=True)
+    shutil.copy(os.path.join(out, "ref.fa"), os.path.join(work, "ref.fa"))
+    rng = random.Random(20261005)
+    seqs = [(n.split()[0], "".join(c if c in "ACGT" else "G" for c in s.upper())) for n, s in read_fasta(os.path.join(work, "ref.fa"))]
+
+    def frag(ins):
+        while True:
+            n, s = rng.choice(seqs)
+            if len(s) < ins + 20:
+                continue
+            o = rng.randrange(0, len(s) - ins)
+            return n, o, s[o:o + ins]
+
+    def planted(s, k):
+        return mutate(s, rng.sample(range(2, len(s) - 2), k), rng)
+    pairs = []
+    for rep in range(2):
+        for ins in (399, 400, 401, 500, 599, 600, 601, 650):
+            for ma, mb in ((0, 0), (1, 0), (0, 2), (2, 2), (1, 1)):
+                n, o, f = frag(ins)
+                pairs.append((f"FR_i{ins}_a{ma}_b{mb}_{n}_{o}", planted(f[:60], ma), planted(rc(f[-60:]), mb)))
+        for ll, lr in ((40, 100), (100, 40), (30, 90), (90, 30)):
+            for ins in (380, 400, 440, 460, 560, 600, 620, 660):
+                for swap in (0, 1):
+                    n, o, f = frag(ins)
+                    left, right = f[:ll], rc(f[-lr:])
+                    pairs.append((f"len{ll}_{lr}_i{ins}_sw{swap}_{n}_{o}", right if swap else left, left if swap else right))
+        for ins in (450, 550):
+            n, o, f = frag(ins)
+            pairs.append((f"outward_i{ins}_{n}_{o}", rc(f[:60]), f[-60:]))
+            n, o, f = frag(ins)
+            pairs.append((f"same_strand_i{ins}_{n}_{o}", f[:60], f[-60:]))
+            n, o, f = frag(ins)
+            pairs.append((f"a_three_mismatches_i{ins}_{n}_{o}", planted(f[:60], 3), rc(f[-60:])))
+            n, o, f = frag(ins)
+            pairs.append((f"b_three_mismatches_i{ins}_{n}_{o}", f[:60], planted(rc(f[-60:]), 3)))
+            n, o, f = frag(ins)
+            pairs.append((f"b_random_i{ins}_{n}_{o}", f[:60], "".join(rng.choice("ACGT") for _ in range(60))))
+            n, o, f = frag(ins)
+            m2 = rc(f[-60:])
+            pairs.append((f"b_seven_N_i{ins}_{n}_{o}", f[:60], m2[:10] + "NNNNNNN" + m2[17:]))
+            pairs.append((f"b_two_N_i{ins}_{n}_{o}", f[:60], m2[:10] + "N" + m2[11:30] + "n" + m2[31:]))
+    with open(os.path.join(work, "pe_a.fa"), "w") as fa, open(os.path.join(work, "pe_b.fa"), "w") as fb:
+        for k, (tag, m1, m2) in enumerate(pairs):
+            fa.write(f">p{k}_{tag}/1\n{m1}\n")
+            fb.write(f">p{k}_{tag}/2\n{m2}\n")
+    sweep = []
+    for L in (27, 28, 30, 31, 32, 33, 36, 38, 39, 40, 41, 44, 48, 50, 60, 64, 75, 90, 100, 120):
+        for mx in sorted(set(range(max(6, L // 3), L - 1, 1 if L <= 44 else 3)) | {2 * (L // 3) - 1, 2 * (L // 3)}):
+            n, o, f = frag(500)
+            m2 = list(f[-L:])
+            lo = rng.randrange(1, mx - 1)
+            for p in (lo, mx):
+                m2[p] = other(m2[p], rng)
+            sweep.append((f"L{L}_lo{lo}_mx{mx}", f[:L], rc("".join(m2))))
+    with open(os.path.join(work, "pe_sweep_a.fa"), "w") as fa, open(os.path.join(work, "pe_sweep_b.fa"), "w") as fb:
+        for k, (tag, m1, m2) in enumerate(sweep):
+            fa.write(f">w{k}_{tag}/1\n{m1}\n")
+            fb.write(f">w{k}_{tag}/2\n{m2}\n")
+    builder, soap = os.path.join(soap_dir, "2bwt-builder"), os.path.join(soap_dir, "soap")
+    if not os.path.exists(os.path.join(work, "ref.fa.index.bwt")):
+        subprocess.run([builder, "ref.fa"], cwd=work, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for r in ("2", "0"):
+        subprocess.run([soap, "-a", "pe_a.fa", "-b", "pe_b.fa", "-D", "ref.fa.index", "-o", f"pe_paired_r{r}.txt", "-2", f"pe_unpaired_r{r}.txt",
+                        "-u", f"pe_unmapped_r{r}.txt", "-m", "400", "-x", "600", "-p", "1", "-M", "4", "-r", r], cwd=work, check=True,
+                       timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([soap, "-a", "pe_sweep_a.fa", "-b", "pe_sweep_b.fa", "-D", "ref.fa.index", "-o", "pe_sweep_paired.txt", "-2",
+                    "pe_sweep_unpaired.txt", "-u", "pe_sweep_unmapped.txt", "-m", "300", "-x", "700", "-p", "1", "-M", "4", "-r", "2"], cwd=work,
+                   check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for n in ("pe_a.fa", "pe_b.fa", "pe_sweep_a.fa", "pe_sweep_b.fa"):
+        shutil.copy(os.path.join(work, n), os.path.join(out, n))
+    for n in ["pe_%s_r%s.txt" % (k, r) for k in ("paired", "unpaired", "unmapped") for r in ("2", "0")] + \
+             ["pe_sweep_%s.txt" % k for k in ("paired", "unpaired", "unmapped")]:
+        with open(os.path.join(work, n), "rb") as a, gzip.GzipFile(os.path.join(out, n + ".gz"), "wb", mtime=0) as b:
+            shutil.copyfileobj(a, b)
+    print("soap paired-end: %d + %d pairs; rows: %s" % (len(pairs), len(sweep), {n: sum(1 for _ in open(os.path.join(work, n)))
+                                                                                     for n in ("pe_paired_r2.txt", "pe_unpaired_r2.txt", "pe_sweep_paired.txt")}))
+
+
+if __name__ == "__main__":
+    import sys
+    import tempfile
+    HERE = os.path.dirname(os.path.abspath(__file__))
+    if sys.argv[1:] == ["pe"]:
+        with tempfile.TemporaryDirectory(prefix="pgx_soap_pe_", dir="/tmp") as scratch:
+            generate_pe(scratch, os.path.join(HERE, "..", "tests", "golden"), "/root/reference/Classify/Runsoap/soap2.21release")
+    else:
+        sys.exit("usage: python3 oracle/gen_goldens_soap.py pe   (the single-end goldens: oracle/gen_goldens.py soap)")

@@ -54,6 +54,15 @@ static int run_soap(int argc, char **argv)
 	size_t n = strlen(ref);
 	if (n > 6 && strcmp(ref + n - 6, ".index") == 0)
 		ref[n - 6] = '\0';
+	/* paired-end: -b B -2 unpaired -m MIN -x MAX (soap.man:29-50; defaults 400 / 600) */
+	const char *b = arg_of(argc, argv, "-b", NULL);
+	if (b) {
+		const int rc = o_soap_pe_files(a, b, ref, o, arg_of(argc, argv, "-2", NULL), u, &opt, atoi(arg_of(argc, argv, "-m", "400")),
+					       atoi(arg_of(argc, argv, "-x", "600")));
+		if (rc == -3)
+			fprintf(stderr, "soap: paired-end mates of fewer than 27 bases are outside what is restated\n");
+		return rc ? 1 : 0;
+	}
 	return o_soap_files(a, ref, o, u, &opt) ? 1 : 0;
 }
 

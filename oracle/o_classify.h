@@ -125,6 +125,9 @@ typedef struct {
 } o_soap_opts;
 int o_soap_files(const char *reads_fa, const char *ref_fa, const char *out_path, const char *unmapped_or_null,
 		 const o_soap_opts *opt);
+/* paired-end mode (soap.man:29-50): -a A -b B -o paired -2 unpaired [-u unmapped] -m MIN -x MAX; -3: a mate under 27 bases */
+int o_soap_pe_files(const char *a_fa, const char *b_fa, const char *ref_fa, const char *out_path, const char *unpaired_path,
+		    const char *unmapped_or_null, const o_soap_opts *opt, int min_ins, int max_ins);
 
 int o_classify_main(int argc, char **argv);
 

@@ -59,6 +59,44 @@ def test_soap_match_modes_match_reference_binary(gold, oracle_bin, tmp_path, mod
     assert unm.read_bytes() == open(os.path.join(g, "unmapped_M%d.txt" % mode), "rb").read()
 
 
+PE_SETS = [("r2", "pe_a.fa", "pe_b.fa", 400, 600, 2, "pe_%s_r2.txt.gz", 458, 1324),
+           ("r0", "pe_a.fa", "pe_b.fa", 400, 600, 0, "pe_%s_r0.txt.gz", 178, 62),
+           ("sweep", "pe_sweep_a.fa", "pe_sweep_b.fa", 300, 700, 2, "pe_sweep_%s.txt.gz", 2332, 171)]
+
+
+@pytest.mark.parametrize("case", PE_SETS, ids=[c[0] for c in PE_SETS])
+def test_soap_paired_end_matches_reference_binary(gold, oracle_bin, tmp_path, case):
+    """`soap -a A -b B -2 unpaired -m MIN -x MAX` (soap.man:29-50) against the rows the closed ELF printed for the pairs of
+    oracle/gen_goldens_soap.py (generate_pe): inserts either side of both limits, mates of unequal length, swapped mates,
+    outward and same-strand pairs, 0-3 planted mismatches, a mate that maps nowhere, N-rich mates, and a sweep of mate
+    lengths 27-120 with two mismatches at swept offsets (the order of the two entries of a row).  Rows as sets per read
+    (the order among a read's rows is the ELF's suffix-array order, a documented deviation); the unmapped list byte for byte."""
+    import gzip
+    tag, a, b, lo, hi, r, names, n_paired, n_unpaired = case
+    g = os.path.join(gold, "soap")
+    o, u2, un = tmp_path / "o.txt", tmp_path / "u2.txt", tmp_path / "un.txt"
+    rc, _, _ = run_cmd([oracle_bin, "soap", "-a", os.path.join(g, a), "-b", os.path.join(g, b), "-D", os.path.join(g, "ref.fa.index"),
+                        "-o", str(o), "-2", str(u2), "-u", str(un), "-m", str(lo), "-x", str(hi), "-r", str(r), "-M", "4"])
+    assert rc == 0
+    for kind, path, n in (("paired", o, n_paired), ("unpaired", u2, n_unpaired)):
+        want = tmp_path / ("want_" + kind)
+        want.write_bytes(gzip.open(os.path.join(g, names % kind), "rb").read())
+        assert soap_rows(str(path)) == soap_rows(str(want)), kind
+        assert sum(1 for _ in open(path)) == n, kind
+    assert un.read_bytes() == gzip.open(os.path.join(g, names % "unmapped"), "rb").read()
+
+
+def test_soap_paired_end_refuses_what_is_not_restated(oracle_bin, gold, tmp_path):
+    """Mates of fewer than 27 bases (the ELF itself crashes on some of them in paired-end runs) are refused, not guessed."""
+    g = os.path.join(gold, "soap")
+    a, b = tmp_path / "a.fa", tmp_path / "b.fa"
+    a.write_text(">p/1\nACGTACGTACGTACGTACGTACG\n")
+    b.write_text(">p/2\nACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    rc, _, err = run_cmd([oracle_bin, "soap", "-a", str(a), "-b", str(b), "-D", os.path.join(g, "ref.fa.index"), "-o", str(tmp_path / "o"),
+                          "-2", str(tmp_path / "u")])
+    assert rc != 0 and b"27" in err
+
+
 # ---------------------------------------------------------------- BLAST mode brute force
 def read_fa(p):
     out = []
