@@ -127,6 +127,12 @@ typedef struct {
 	int repeat_mode;           /* -r 0|1|2, default 1 */
 	int max_n;                 /* -n, default 5 */
 	int report_id;             /* -t: the read's 0-based ordinal in the file instead of its name */
+	/* paired-end run (soap.man:29-50; the reference's pipeline does not use it, README.md:134): read i of -a is the mate of
+	 * read i of -b.  NULL reads_b_path = single-end.  Mates of 27 to 256 bases, -M 4, no -t (anything else: PGX_E_LIMIT /
+	 * PGX_E_ARG, the ELF's behaviour there was not observed or is a crash) */
+	const char *reads_b_path;  /* -b */
+	const char *unpaired_path; /* -2: the placements of mates without a valid pair (required with -b) */
+	int min_insert, max_insert; /* -m / -x, both 0 = soap's defaults 400 / 600 */
 } pgx_soap_opts;
 int pgx_soap_index(const char *fasta_path); /* writes <fasta>.index.pgxdb */
 int pgx_soap_run(const pgx_soap_opts *opts);

@@ -60,7 +60,7 @@ static int run_soap(int argc, char **argv)
 		const int rc = o_soap_pe_files(a, b, ref, o, arg_of(argc, argv, "-2", NULL), u, &opt, atoi(arg_of(argc, argv, "-m", "400")),
 					       atoi(arg_of(argc, argv, "-x", "600")));
 		if (rc == -3)
-			fprintf(stderr, "soap: paired-end mates of fewer than 27 bases are outside what is restated\n");
+			fprintf(stderr, "soap: paired-end mates of fewer than 27 or more than 256 bases are outside what is restated\n");
 		return rc ? 1 : 0;
 	}
 	return o_soap_files(a, ref, o, u, &opt) ? 1 : 0;

@@ -371,7 +371,8 @@ static int soap_pair_ok(const shit *a, const shit *b, int32_t La, int level, int
  * reference's pipeline never calls it (README.md:134 is single-ended); every rule below was observed by running the ELF
  * (oracle/gen_goldens_soap.py, paired-end part) and is pinned by tests/golden/soap/pe_*:
  *   - pair i = read i of A with read i of B; a mate shorter than 27 bases is outside what is restated (the ELF places
- *     some of them beside their partner and crashes on others): such input is refused (-3);
+ *     some of them beside their partner and crashes on others), and so is one above 256 bases (-l; not observed): such input
+ *     is refused (-3);
  *   - pairs are looked for among the placements with at most k mismatches of either mate, k = 0, then 1, then 2: the first
  *     k that gives a valid pair decides, and all valid pairs at that k are the pair's result (with a mate whose best
  *     placement has two mismatches that is every placement of both mates);
@@ -419,7 +420,7 @@ int o_soap_pe_files(const char *a_fa, const char *b_fa, const char *ref_fa, cons
 		int nna, nnb;
 		soap_read_strands(&ra, ri, &fa, &va, &La, &nna);
 		soap_read_strands(&rb, ri, &fb, &vb, &Lb, &nnb);
-		if (La < 27 || Lb < 27) {
+		if (La < 27 || Lb < 27 || La > 256 || Lb > 256) {
 			rc = -3;
 		} else {
 			size_t nha = nna <= opt->max_n ? soap_enum(&ix, fa, va, La, &ha, &capa, 1) : 0;

@@ -75,7 +75,8 @@ class _BlastnOpts(C.Structure):
 class _SoapOpts(C.Structure):
     _fields_ = [("reads_path", C.c_char_p), ("db_prefix", C.c_char_p), ("out_path", C.c_char_p),
                 ("unmapped_path", C.c_char_p), ("match_mode", C.c_int), ("repeat_mode", C.c_int), ("max_n", C.c_int),
-                ("report_id", C.c_int)]
+                ("report_id", C.c_int), ("reads_b_path", C.c_char_p), ("unpaired_path", C.c_char_p), ("min_insert", C.c_int),
+                ("max_insert", C.c_int)]
 
 
 HIT_DTYPE = np.dtype([("read", "<i4"), ("subject", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"),
@@ -522,9 +523,10 @@ def soap_index(fasta):
     _check(lib().pgx_soap_index(_b(fasta)))
 
 
-def soap(a, D, o, u=None, M=4, r=1, n=5, t=False):
-    """`soap -a reads -D ref.index -o out [-u unmapped] -M 4 -r 1 -n 5` (reference README.md:134)."""
-    opts = _SoapOpts(_b(a), _b(D), _b(o), _b(u), M, r, n, int(bool(t)))
+def soap(a, D, o, u=None, M=4, r=1, n=5, t=False, b=None, unpaired=None, m=400, x=600):
+    """`soap -a reads -D ref.index -o out [-u unmapped] -M 4 -r 1 -n 5` (reference README.md:134); paired-end with
+    `b` (-b), `unpaired` (-2), `m` / `x` (-m / -x), soap.man:29-50."""
+    opts = _SoapOpts(_b(a), _b(D), _b(o), _b(u), M, r, n, int(bool(t)), _b(b), _b(unpaired), m, x)
     _check(lib().pgx_soap_run(C.byref(opts)))
 
 

@@ -1,5 +1,6 @@
 // soap — `soap -a reads -D ref.fa.index -o out [-u unmapped] [-M 4] [-r 0|1|2] [-n 5] [-p N]`
 // (reference README.md:134, soap.man:29-83). -p is accepted and ignored: the GPU does the work.
+// Paired-end: `-b mates -2 unpaired [-m 400] [-x 600]` (soap.man:29-50).
 #include <cstdio>
 #include <cstdlib>
 #include <unistd.h>
@@ -7,7 +8,7 @@
 
 int main(int argc, char **argv)
 {
-	pgx_soap_opts o = { nullptr, nullptr, nullptr, nullptr, 4, 1, 5, 0 };
+	pgx_soap_opts o = { nullptr, nullptr, nullptr, nullptr, 4, 1, 5, 0, nullptr, nullptr, 400, 600 };
 	int c;
 	while ((c = getopt(argc, argv, "a:D:o:u:M:r:n:p:tb:2:m:x:l:s:v:g:R")) != -1) {
 		switch (c) {
@@ -20,8 +21,12 @@ int main(int argc, char **argv)
 		case 'n': o.max_n = atoi(optarg); break;
 		case 't': o.report_id = 1; break;
 		case 'p': break;
-		case 'b': case '2': case 'm': case 'x': case 'R':
-			fprintf(stderr, "soap: paired-end options are not implemented\n");
+		case 'b': o.reads_b_path = optarg; break;
+		case '2': o.unpaired_path = optarg; break;
+		case 'm': o.min_insert = atoi(optarg); break;
+		case 'x': o.max_insert = atoi(optarg); break;
+		case 'R':
+			fprintf(stderr, "soap: -R (long-insert pairs, RF orientation) is not implemented\n");
 			return 1;
 		default: break;
 		}

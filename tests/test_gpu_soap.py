@@ -118,3 +118,110 @@ def test_soap_short_reads_and_seeded_mismatches_match_oracle(pg, oracle_bin, tmp
         assert (tmp_path / "p.txt").read_bytes() == (tmp_path / "o.txt").read_bytes(), r
         assert (tmp_path / "pu.txt").read_bytes() == (tmp_path / "ou.txt").read_bytes(), r
     assert (tmp_path / "p.txt").stat().st_size > 10000
+
+
+PE_SETS = [("r2", "pe_a.fa", "pe_b.fa", 400, 600, 2, "pe_%s_r2.txt.gz", 458, 1324),
+           ("r0", "pe_a.fa", "pe_b.fa", 400, 600, 0, "pe_%s_r0.txt.gz", 178, 62),
+           ("sweep", "pe_sweep_a.fa", "pe_sweep_b.fa", 300, 700, 2, "pe_sweep_%s.txt.gz", 2332, 171)]
+
+
+@pytest.mark.parametrize("case", PE_SETS, ids=[c[0] for c in PE_SETS])
+def test_soap_paired_end_equals_the_reference_binary(pg, gold, oracle_bin, tmp_path, case):
+    """`soap -a A -b B -2 unpaired -m MIN -x MAX` (soap.man:29-50): the three files against what the closed ELF printed for the
+    same pairs (sets per read; the unmapped list byte for byte) and against the checker byte for byte."""
+    import gzip
+    tag, a, b, lo, hi, r, names, n_paired, n_unpaired = case
+    g = os.path.join(gold, "soap")
+    ref = tmp_path / "ref.fa"
+    ref.write_bytes(open(os.path.join(g, "ref.fa"), "rb").read())
+    pg.soap_index(str(ref))
+    o, u2, un = tmp_path / "o.txt", tmp_path / "u2.txt", tmp_path / "un.txt"
+    pg.soap(os.path.join(g, a), str(ref) + ".index", str(o), u=str(un), r=r, b=os.path.join(g, b), unpaired=str(u2), m=lo, x=hi)
+    for kind, path, n in (("paired", o, n_paired), ("unpaired", u2, n_unpaired)):
+        want = tmp_path / ("want_" + kind)
+        want.write_bytes(gzip.open(os.path.join(g, names % kind), "rb").read())
+        assert rows(path) == rows(want), kind
+        assert sum(1 for _ in open(path)) == n, kind
+    assert un.read_bytes() == gzip.open(os.path.join(g, names % "unmapped"), "rb").read()
+    oo, ou2, oun = tmp_path / "oo.txt", tmp_path / "ou2.txt", tmp_path / "oun.txt"
+    assert run_cmd([oracle_bin, "soap", "-a", os.path.join(g, a), "-b", os.path.join(g, b), "-D", str(ref) + ".index", "-o", str(oo), "-2",
+                    str(ou2), "-u", str(oun), "-m", str(lo), "-x", str(hi), "-r", str(r)])[0] == 0
+    assert o.read_bytes() == oo.read_bytes() and u2.read_bytes() == ou2.read_bytes() and un.read_bytes() == oun.read_bytes()
+
+
+@pytest.mark.parametrize("seed", [11])
+def test_soap_paired_end_seeded_pairs_match_oracle(pg, oracle_bin, tmp_path, seed):
+    """Pairs cut from a repetitive synthetic reference (each sequence twice, the copy with a few substitutions: several valid
+    pairs per read pair, levels 0-2 all in use), all three -r modes, through the executable: bytes of the checker."""
+    import random
+    rng = random.Random(seed)
+    db = tmp_path / "db0.fa"
+    assert run_cmd([oracle_bin, "synth", "db", "--out", str(db), "--n-seq", "120", "--seq-len", "1400", "--n-genus", "8"])[0] == 0
+    seqs = [l.strip() for l in open(db) if not l.startswith(">")]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rcs = lambda s: "".join(comp[c] for c in reversed(s))
+    with open(tmp_path / "db.fa", "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">r%d\n%s\n" % (i, s))
+            w = list(s)
+            for p in rng.sample(range(len(w)), 12):
+                w[p] = rng.choice([c for c in "ACGT" if c != w[p]])
+            f.write(">r%d_copy\n%s\n" % (i, "".join(w)))
+    fa, fb = open(tmp_path / "a.fa", "w"), open(tmp_path / "b.fa", "w")
+    for i in range(1200):
+        s = rng.choice(seqs)
+        ins = rng.choice([380, 399, 400, 450, 500, 600, 601, 640])
+        la, lb = rng.choice([27, 32, 33, 40, 50, 75, 100, 150, 256]), rng.choice([27, 31, 32, 38, 39, 50, 90, 120, 256])
+        o = rng.randrange(0, len(s) - ins)
+        f = s[o:o + ins]
+        m1, m2 = list(f[:la]), list(rcs(f[-lb:]))
+        for m in (m1, m2):
+            for p in rng.sample(range(len(m)), rng.choice([0, 0, 1, 2, 2, 3])):
+                m[p] = rng.choice([c for c in "ACGT" if c != m[p]])
+        m1, m2 = "".join(m1), "".join(m2)
+        kind = rng.random()
+        if kind < 0.1:
+            m1, m2 = m2, m1
+        elif kind < 0.15:
+            m2 = rcs(m2)
+        elif kind < 0.2:
+            m2 = m2[:5] + "N" * 3 + m2[8:]
+        elif kind < 0.23:
+            m1 = m1[:5] + "N" * 6 + m1[11:]
+        fa.write(">p%d/1\n%s\n" % (i, m1))
+        fb.write(">p%d/2\n%s\n" % (i, m2))
+    fa.close()
+    fb.close()
+    pg.soap_index(str(tmp_path / "db.fa"))
+    sizes = []
+    for r in (2, 1, 0):
+        p = subprocess.run([os.path.join(BIN, "soap"), "-a", str(tmp_path / "a.fa"), "-b", str(tmp_path / "b.fa"), "-D",
+                            str(tmp_path / "db.fa") + ".index", "-o", str(tmp_path / "p.txt"), "-2", str(tmp_path / "p2.txt"), "-u",
+                            str(tmp_path / "pu.txt"), "-m", "400", "-x", "600", "-r", str(r), "-p", "8"])
+        assert p.returncode == 0
+        assert run_cmd([oracle_bin, "soap", "-a", str(tmp_path / "a.fa"), "-b", str(tmp_path / "b.fa"), "-D", str(tmp_path / "db.fa") + ".index",
+                        "-o", str(tmp_path / "o.txt"), "-2", str(tmp_path / "o2.txt"), "-u", str(tmp_path / "ou.txt"), "-m", "400", "-x", "600",
+                        "-r", str(r)])[0] == 0
+        for x, y in (("p.txt", "o.txt"), ("p2.txt", "o2.txt"), ("pu.txt", "ou.txt")):
+            assert (tmp_path / x).read_bytes() == (tmp_path / y).read_bytes(), (r, x)
+        sizes.append([(tmp_path / x).stat().st_size for x in ("p.txt", "p2.txt", "pu.txt")])
+    assert min(sizes[0]) > 10000 and sizes[2][2] > sizes[0][2]   # -r 0 sends the ambiguous pairs to the unmapped file
+
+
+def test_soap_paired_end_refusals(pg, gold, tmp_path):
+    from pangea_plus_amd import _capi
+    g = os.path.join(gold, "soap")
+    ref = tmp_path / "ref.fa"
+    ref.write_bytes(open(os.path.join(g, "ref.fa"), "rb").read())
+    pg.soap_index(str(ref))
+    a, b = os.path.join(g, "pe_a.fa"), os.path.join(g, "pe_b.fa")
+    kw = dict(u=None, r=2, b=b, unpaired=str(tmp_path / "u2"))
+    for bad, status in ((dict(M=1), -1), (dict(t=True), -1), (dict(unpaired=None), -1)):
+        with pytest.raises(_capi.PangeaError) as e:
+            pg.soap(a, str(ref) + ".index", str(tmp_path / "o"), **{**kw, **bad})
+        assert e.value.status == status, bad
+    short = tmp_path / "short.fa"
+    short.write_text(">p/2\nACGTACGTACGTACGTACGTACG\n")
+    with pytest.raises(_capi.PangeaError) as e:
+        pg.soap(a, str(ref) + ".index", str(tmp_path / "o"), **{**kw, "b": str(short)})
+    assert e.value.status == -7 and not os.path.exists(tmp_path / "o")
