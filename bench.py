@@ -123,6 +123,7 @@ def inclusive(pg, _capi, cfg, db, tmp, first, n):
     t.append(time.perf_counter())
     hits, recs = _capi.classify_consensus(db, r, p)
     t.append(time.perf_counter())
+    st = _capi.stage_times()
     n_text = _capi.consensus_format_file(db, r, hits, recs, out)   # rendered on the device, written piece by piece
     t.append(time.perf_counter())
     size = os.path.getsize(fa) + os.path.getsize(rf)
@@ -131,7 +132,8 @@ def inclusive(pg, _capi, cfg, db, tmp, first, n):
     return {"value": n / (t[-1] - t[0]), "unit": "reads/s",
             "sample": "%d reads: %.0f MB of FASTA + RDP text in, %.0f MB of consensus text out" % (n, size / 1e6, n_text / 1e6),
             "stages_s": {"fasta_to_hbm": t[1] - t[0], "rdp_to_hbm": t[2] - t[1], "classify_consensus": t[3] - t[2],
-                         "consensus_text_to_file": t[4] - t[3]}}
+                         "consensus_text_to_file": t[4] - t[3]},
+            "classify_consensus_kernels_ms": st.total_ms, "classify_consensus_attempts": st.attempts}
 
 
 def main():

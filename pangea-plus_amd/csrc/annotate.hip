@@ -580,6 +580,8 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 		// OTU ids for megaclust: one per distinct lineage text, plus one for the empty text of an empty line
 		std::unordered_map<std::string, uint32_t> lin_id;
 		std::vector<uint32_t> subj_lin(n);
+		std::lock_guard<std::mutex> fmt_lock(db->fmt_mu);
+		db->lin_blob_ready = false; // (the formatters' copy of these texts in HBM is made again at its next use)
 		db->lin_text.clear();
 		for (size_t i = 0; i < n; i++)
 			subj_lin[i] = intern_into(lin_id, db->lin_text, db->lineage[i]);

@@ -319,6 +319,32 @@ __global__ void k_fmt_rows(FmtView v, uint64_t j0, uint64_t j1, unsigned long lo
 static bool build_score_table(const pgx_db *db, const pgx_reads *reads, int64_t n, bool trim_bits, bool gapped, std::vector<uint32_t> &len_slot,
 			      std::vector<uint32_t> &slot_base, std::vector<uint32_t> &score_off, std::string &score_blob);
 
+// one text per id, back to back, in HBM: made once per handle (engine.hpp: pgx_db::fmt_mu)
+static int text_table_once(const std::vector<std::string> &texts, std::mutex &mu, bool &ready, DevBuf<unsigned char> &d_blob, DevBuf<uint32_t> &d_off)
+{
+	std::lock_guard<std::mutex> lock(mu);
+	if (ready)
+		return 0;
+	std::string blob;
+	std::vector<uint32_t> off(texts.size() + 1, 0);
+	size_t total = 0;
+	for (auto &t : texts)
+		total += t.size();
+	if (total > 0xFFFFFFFFull)
+		return fail(PGX_E_LIMIT, "the texts of a formatter table exceed 4 GB");
+	blob.reserve(total);
+	for (size_t i = 0; i < texts.size(); i++) {
+		blob += texts[i];
+		off[i + 1] = (uint32_t)blob.size();
+	}
+	PGX_TRY(d_blob.alloc(blob.size() ? blob.size() : 1));
+	PGX_TRY(d_blob.upload((const unsigned char *)blob.data(), blob.size()));
+	PGX_TRY(d_off.alloc(off.size()));
+	PGX_TRY(d_off.upload(off.data(), off.size()));
+	ready = true;
+	return 0;
+}
+
 // renders the whole table; `sink` receives consecutive pieces of text
 int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads,
 		       const std::function<int(const char *, size_t)> &sink)
@@ -327,13 +353,7 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	const uint64_t H = (uint64_t)h->n_hits;
 	if (H == 0 || h->n_reads == 0)
 		return 0;
-	// subject ids
-	std::string id_blob;
-	std::vector<uint32_t> id_off((size_t)db->n_seq + 1, 0);
-	for (size_t i = 0; i < (size_t)db->n_seq; i++) {
-		id_blob += db->ids[i];
-		id_off[i + 1] = (uint32_t)id_blob.size();
-	}
+	PGX_TRY(text_table_once(db->ids, db->fmt_mu, db->id_blob_ready, db->d_id_blob, db->d_id_off)); // subject ids
 	// read names: the batch's own compact copy in HBM (seqdb.hip); a batch without one (older callers) gets it made here
 	std::string name_blob;
 	std::vector<uint32_t> name_off;
@@ -354,8 +374,8 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 		PGX_TRY(format_hits_text_host(h, db, reads, t));
 		return sink(t.s.data(), t.s.size());
 	}
-	DevBuf<unsigned char> d_id_blob, d_name_blob, d_score_blob, d_out;
-	DevBuf<uint32_t> d_id_off, d_name_off, d_len_slot, d_slot_base, d_score_off;
+	DevBuf<unsigned char> d_name_blob, d_score_blob, d_out;
+	DevBuf<uint32_t> d_name_off, d_len_slot, d_slot_base, d_score_off;
 	auto up_bytes = [](DevBuf<unsigned char> &d, const std::string &s) -> int {
 		PGX_TRY(d.alloc(s.size() ? s.size() : 1));
 		return d.upload((const unsigned char *)s.data(), s.size());
@@ -364,8 +384,6 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 		PGX_TRY(d.alloc(v.size() ? v.size() : 1));
 		return d.upload(v.data(), v.size());
 	};
-	PGX_TRY(up_bytes(d_id_blob, id_blob));
-	PGX_TRY(up_u32(d_id_off, id_off));
 	if (!reads->synthetic && !dev_names) {
 		PGX_TRY(up_bytes(d_name_blob, name_blob));
 		PGX_TRY(up_u32(d_name_off, name_off));
@@ -382,8 +400,8 @@ int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *rea
 	v.name_blob = reads->synthetic ? nullptr : (dev_names ? reads->d_names.data() : d_name_blob.data());
 	v.name_off = dev_names ? reads->d_name_at.data() : d_name_off.data();
 	v.first = (unsigned long long)reads->first;
-	v.id_blob = d_id_blob.data();
-	v.id_off = d_id_off.data();
+	v.id_blob = db->d_id_blob.data();
+	v.id_off = db->d_id_off.data();
 	v.len_slot = d_len_slot.data();
 	v.slot_base = d_slot_base.data();
 	v.score_off = d_score_off.data();
@@ -561,12 +579,9 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 	if (!build_score_table(db, reads, n, true, hits->gapped, len_slot, slot_base, score_off, score_blob))
 		return false;
 	auto run = [&]() -> int {
-		std::string lin_blob, name_blob;
-		std::vector<uint32_t> lin_off(db->lin_text.size() + 1, 0), name_off;
-		for (size_t i = 0; i < db->lin_text.size(); i++) {
-			lin_blob += db->lin_text[i];
-			lin_off[i + 1] = (uint32_t)lin_blob.size();
-		}
+		std::string name_blob;
+		std::vector<uint32_t> name_off;
+		PGX_TRY(text_table_once(db->lin_text, db->fmt_mu, db->lin_blob_ready, db->d_lin_blob, db->d_lin_off));
 		const bool dev_names = !reads->synthetic && reads->d_name_at.base != nullptr;
 		if (!reads->synthetic && !dev_names) {
 			name_off.assign((size_t)n + 1, 0);
@@ -575,8 +590,8 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 				name_off[(size_t)r + 1] = (uint32_t)name_blob.size();
 			}
 		}
-		DevBuf<unsigned char> d_lin_blob, d_name_blob, d_score_blob, d_out;
-		DevBuf<uint32_t> d_lin_off, d_name_off, d_len_slot, d_slot_base, d_score_off;
+		DevBuf<unsigned char> d_name_blob, d_score_blob, d_out;
+		DevBuf<uint32_t> d_name_off, d_len_slot, d_slot_base, d_score_off;
 		DevBuf<pgx_consensus_rec> d_recs;
 		auto up_bytes = [](DevBuf<unsigned char> &d, const std::string &s) -> int {
 			PGX_TRY(d.alloc(s.size() ? s.size() : 1));
@@ -586,8 +601,6 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 			PGX_TRY(d.alloc(v.size() ? v.size() : 1));
 			return d.upload(v.data(), v.size());
 		};
-		PGX_TRY(up_bytes(d_lin_blob, lin_blob));
-		PGX_TRY(up_u32(d_lin_off, lin_off));
 		if (!reads->synthetic && !dev_names) {
 			PGX_TRY(up_bytes(d_name_blob, name_blob));
 			PGX_TRY(up_u32(d_name_off, name_off));
@@ -606,8 +619,8 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 		c.f.name_blob = reads->synthetic ? nullptr : (dev_names ? reads->d_names.data() : d_name_blob.data());
 		c.f.name_off = dev_names ? reads->d_name_at.data() : d_name_off.data();
 		c.f.first = (unsigned long long)reads->first;
-		c.f.id_blob = d_lin_blob.data();
-		c.f.id_off = d_lin_off.data();
+		c.f.id_blob = db->d_lin_blob.data();
+		c.f.id_off = db->d_lin_off.data();
 		c.f.len_slot = d_len_slot.data();
 		c.f.slot_base = d_slot_base.data();
 		c.f.score_off = d_score_off.data();

@@ -18,6 +18,7 @@
 //                 (rank,name) agreement with the RDP assignment per hit and the order-dependent
 //                 arg-max with the Perl's string comparisons.
 #include <algorithm>
+#include <chrono>
 
 #include "bitops.hpp"
 #include "consensus_core.hpp"
@@ -1931,7 +1932,9 @@ struct Workspace {
 	GappedWork gapped;
 	DustBufs dust; // S3d computed inside a search (pgx_db_set_dust_each_search) lands here, never in the caller's batch
 	pgx_hits hits; // used when the caller does not keep the hit table
-	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0, table_hint = 0;
+	uint64_t hit_cap_hint = 0, ovf_cap_hint = 0;
+	double table_per_read_hint = 0.0; // the hit table belongs to the caller and is made per call: sized per read, not by the largest batch seen
+	                                  // (a 2 M-read batch after 10 M-read ones used to allocate -- and map -- the 10 M table: 25 ms)
 	pgx_stage_times times;
 	int device = -1;
 	~Workspace()
@@ -1969,6 +1972,13 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	if (rdp && rdp->n != rd->n)
 		return fail(PGX_E_ARG, "RDP stream holds %lld reads, batch holds %lld", (long long)rdp->n, (long long)rd->n);
 	std::lock_guard<std::mutex> lock(db->search_mu);
+	static const bool laps_on = getenv("PGX_CALL_LAPS") != nullptr; // host time of the call's phases, nothing synchronised for it
+	const auto lap_t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (laps_on)
+			fprintf(stderr, "[pgx lap] %8.2f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lap_t0).count(), what);
+	};
+	trace_point("search_pipeline: entered");
 	Workspace *wsp = nullptr;
 	PGX_TRY(workspace_of(db, &wsp));
 	Workspace &ws = *wsp;
@@ -2004,7 +2014,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	// step whether one was too small, and the step is then repeated with larger tables
 	uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 40, 1 << 16) + 256ull * 8 * kWavesPerBlock * kChunk, ws.hit_cap_hint);
 	uint64_t ovf_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) / 4, 1 << 16), ws.ovf_cap_hint);
-	uint64_t table_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 36, 1 << 16), ws.table_hint);
+	uint64_t table_cap = std::max<uint64_t>(std::max<uint64_t>(std::max(n, ns) * 36, 1 << 16), (uint64_t)((double)std::max(n, ns) * ws.table_per_read_hint) + 1);
 	DevBuf<pgx_hit> &scratch = ws.scratch, &ovf = ws.ovf;
 	DevBuf<uint32_t> &read_start = ws.read_start;
 	PGX_TRY(read_start.ensure(std::max(n, ns)));
@@ -2020,6 +2030,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	PGX_TRY(ws.cursor.ensure(ns));
 	PGX_TRY(ws.big_list.ensure(n));
 	PGX_TRY(ws.mid_list.ensure(n + 64ull * kWavesPerBlock * 256 * 8)); // + one open chunk per wave
+	trace_point("search_pipeline: lists ready");
 	const ConsView cv = cons_view(db, rdp);
 	const int lds_ok = rd->max_len <= 65535 ? 1 : 0;
 	uint64_t H = 0, H_ovf = 0;
@@ -2040,7 +2051,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			return fail(PGX_E_LIMIT, "hit tables did not settle after %d attempts", attempt);
 		PGX_TRY(scratch.ensure(cap));
 		PGX_TRY(ovf.ensure(ovf_cap));
+		trace_point("search_pipeline: seed tables ready");
 		PGX_TRY(out->d_hits.ensure(table_cap));
+		trace_point("search_pipeline: hit table ready");
 		cap = scratch.n;
 		ovf_cap = ovf.n;
 		if (dv.gapped) {
@@ -2064,6 +2077,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		ov.ovf_cap = ovf_cap;
 		ov.counters = ws.counters.data();
 		uint32_t *big_count = reinterpret_cast<uint32_t *>(ws.counters.data() + 8), *mid_count = reinterpret_cast<uint32_t *>(ws.counters.data() + 9);
+		trace_point("search_pipeline: tables ready");
+		lap("tables ready");
 		ws.ev.mark(0, st);
 		uint32_t *rc_ptr = split ? ws.piece_cnt.data() : out->d_read_cnt.data(), *rs_ptr = read_start.data();
 		for (const pgx_reads::SearchClass &c0 : classes) {
@@ -2170,7 +2185,9 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 			PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 2, ws.gapped.big_count.data() + 4, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st)); // ([5]: below)
 		}
 		PGX_HIP(hipMemcpyAsync(h_cnt + kNCounters + 1, out->d_read_off.data() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		lap("step enqueued");
 		PGX_HIP(hipStreamSynchronize(st));
+		lap("step finished");
 		H_ovf = h_cnt[4];
 		H = h_cnt[5] + H_ovf;
 		// (either list of the gapped stage's first tier may have outgrown its buffer: both have the capacity of list A's)
@@ -2199,7 +2216,7 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 	// h_cnt[0] counts reserved slots (chunks), h_cnt[5] the hits actually stored there
 	ws.hit_cap_hint = std::max<uint64_t>(ws.hit_cap_hint, h_cnt[0] + h_cnt[0] / 16);
 	ws.ovf_cap_hint = std::max<uint64_t>(ws.ovf_cap_hint, H_ovf + H_ovf / 16);
-	ws.table_hint = std::max<uint64_t>(ws.table_hint, H + H / 16);
+	ws.table_per_read_hint = std::max(ws.table_per_read_hint, (double)(H + H / 16) / (double)std::max(n, ns));
 	out->n_hits = (int64_t)H;
 	out->gapped = dv.gapped != 0;
 	tm.hits = (int64_t)H;
@@ -2241,6 +2258,8 @@ int search_pipeline(pgx_db *db, pgx_reads *rd, const pgx_rdp *rdp, pgx_hits *out
 		tm.total_ms += extra;
 	}
 	t_times = tm;
+	lap("done");
+	trace_point("search_pipeline: done");
 	return 0;
 }
 
@@ -2300,6 +2319,7 @@ int pgx_classify_consensus(pgx_db *db, pgx_reads *reads, const pgx_rdp *rdp, pgx
 			rc = fail(PGX_E_ARG, "record buffer too small");
 		else
 			rc = ws->recs.download(out, (size_t)reads->n);
+		trace_point("pgx_classify_consensus: records downloaded");
 	}
 	if (hits_out) {
 		if (rc < 0)

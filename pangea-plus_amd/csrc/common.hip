@@ -1,4 +1,10 @@
 // Status/error text, device selection, small host utilities.
+#include <chrono>
+#include <cstring>
+#include <vector>
+#include <thread>
+#include <mutex>
+#include <atomic>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -172,14 +178,136 @@ int write_text_file(const char *path, const std::string &s)
 	return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------ staged copies
+// kStageWorkers host threads, each with its own stream and two pinned buffers: a worker copies stripe k of the range into
+// one buffer and starts its DMA while it fills the other.  The ring is made at the first large copy and lives as long as the
+// process (pinning 64 MB costs milliseconds: not per call); one large copy at a time per process.
+namespace {
+constexpr int kStageWorkers = 4;
+constexpr size_t kStageStripe = 8u << 20;
+struct StageRing {
+	std::mutex mu;
+	int device = -1;
+	char *pin[kStageWorkers][2] = {};
+	hipStream_t stream[kStageWorkers] = {};
+	hipEvent_t done[kStageWorkers][2] = {};
+	bool ready = false;
+	int init(int dev)
+	{
+		if (ready && device == dev)
+			return 0;
+		if (ready) // (the process moved to another device: streams and events belong to the old one)
+			for (int w = 0; w < kStageWorkers; w++) {
+				(void)hipStreamDestroy(stream[w]);
+				for (int b = 0; b < 2; b++)
+					(void)hipEventDestroy(done[w][b]);
+			}
+		for (int w = 0; w < kStageWorkers; w++) {
+			for (int b = 0; b < 2; b++) {
+				if (!pin[w][b])
+					PGX_HIP(hipHostMalloc((void **)&pin[w][b], kStageStripe, hipHostMallocDefault));
+				PGX_HIP(hipEventCreateWithFlags(&done[w][b], hipEventDisableTiming));
+			}
+			PGX_HIP(hipStreamCreateWithFlags(&stream[w], hipStreamNonBlocking));
+		}
+		device = dev;
+		ready = true;
+		return 0;
+	}
+};
+StageRing g_ring;
+
+int staged_copy(char *device_p, char *host_p, size_t bytes, bool to_device)
+{
+	PGX_TRY(require_device());
+	// (what is in flight on the caller's streams and touches the device range must be over: hipMemcpy waited for it, too)
+	PGX_HIP(hipDeviceSynchronize());
+	std::lock_guard<std::mutex> lock(g_ring.mu);
+	int dev = 0;
+	PGX_HIP(hipGetDevice(&dev));
+	PGX_TRY(g_ring.init(dev));
+	const size_t n_stripes = (bytes + kStageStripe - 1) / kStageStripe;
+	const int workers = (int)std::min<size_t>(kStageWorkers, n_stripes);
+	std::atomic<int> failed{ 0 };
+	auto work = [&](int w) {
+		if (hipSetDevice(dev) != hipSuccess) {
+			failed = 1;
+			return;
+		}
+		int round = 0;
+		for (size_t k = (size_t)w; k < n_stripes && !failed; k += (size_t)workers, round++) {
+			const int b = round & 1;
+			const size_t o = k * kStageStripe, len = std::min(kStageStripe, bytes - o);
+			char *pin = g_ring.pin[w][b];
+			if (round >= 2 && hipEventSynchronize(g_ring.done[w][b]) != hipSuccess) // the buffer's earlier DMA
+				failed = 1;
+			if (to_device) {
+				memcpy(pin, host_p + o, len);
+				if (hipMemcpyAsync(device_p + o, pin, len, hipMemcpyHostToDevice, g_ring.stream[w]) != hipSuccess)
+					failed = 1;
+				if (hipEventRecord(g_ring.done[w][b], g_ring.stream[w]) != hipSuccess)
+					failed = 1;
+			} else {
+				// (the copy out of the pinned buffer needs its DMA finished: stripe k's DMA runs while stripe k - workers' bytes
+				// are copied out)
+				if (hipMemcpyAsync(pin, device_p + o, len, hipMemcpyDeviceToHost, g_ring.stream[w]) != hipSuccess)
+					failed = 1;
+				if (hipEventRecord(g_ring.done[w][b], g_ring.stream[w]) != hipSuccess)
+					failed = 1;
+				if (round >= 1) {
+					const size_t ko = (k - (size_t)workers) * kStageStripe;
+					if (hipEventSynchronize(g_ring.done[w][b ^ 1]) != hipSuccess)
+						failed = 1;
+					memcpy(host_p + ko, g_ring.pin[w][b ^ 1], std::min(kStageStripe, bytes - ko));
+				}
+			}
+		}
+		if (!to_device && round >= 1 && !failed) { // the worker's last stripe
+			const size_t k = (size_t)w + (size_t)(round - 1) * (size_t)workers, o = k * kStageStripe;
+			if (hipEventSynchronize(g_ring.done[w][(round - 1) & 1]) != hipSuccess)
+				failed = 1;
+			memcpy(host_p + o, g_ring.pin[w][(round - 1) & 1], std::min(kStageStripe, bytes - o));
+		}
+		if (hipStreamSynchronize(g_ring.stream[w]) != hipSuccess)
+			failed = 1;
+	};
+	std::vector<std::thread> th;
+	try {
+		for (int w = 1; w < workers; w++)
+			th.emplace_back(work, w);
+	} catch (...) {
+		failed = 1; // (no thread to be had)
+	}
+	if (!failed)
+		work(0);
+	for (auto &t : th)
+		t.join();
+	if (failed)
+		return fail(PGX_E_NODEVICE, "staged copy of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+	return 0;
+}
+} // namespace
+
+int staged_upload(void *dst_device, const void *src_host, size_t bytes)
+{
+	return staged_copy((char *)dst_device, const_cast<char *>((const char *)src_host), bytes, true);
+}
+int staged_download(void *dst_host, const void *src_device, size_t bytes)
+{
+	return staged_copy(const_cast<char *>((const char *)src_device), (char *)dst_host, bytes, false);
+}
+
 // debugging aid (PGX_TRACE=1): synchronise and report after a stage, so a device fault names its kernel
 void trace_point(const char *what)
 {
 	static const bool on = getenv("PGX_TRACE") != nullptr;
 	if (!on)
 		return;
+	static const auto t0 = std::chrono::steady_clock::now();
 	const hipError_t e = hipDeviceSynchronize();
-	fprintf(stderr, "[pgx trace] %s: %s\n", what, hipGetErrorString(e));
+	fprintf(stderr, "[pgx trace] %9.2f ms  %s: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what,
+		hipGetErrorString(e));
 	fflush(stderr);
 }
 
@@ -188,7 +316,7 @@ void trace_point(const char *what)
 extern "C" {
 
 const char *pgx_last_error(void) { return pgx::get_error(); }
-const char *pgx_version(void) { return "pangea_hip 0.1 (gfx950; pgx-blastn v1)"; }
+const char *pgx_version(void) { return "pangea_hip 0.4 (gfx950; pgx-blastn v2)"; }
 
 int pgx_device_count(void)
 {

@@ -53,6 +53,14 @@ template <typename F> int guard(const char *what, F &&body)
 	}
 }
 
+// Large copies between host memory and HBM go through the process's ring of pinned buffers (common.hip): handing the
+// runtime a large PAGEABLE range (a file mapping, a vector, a numpy array) makes it pin those pages for the copy, and the
+// driver then stops every queue of the process when the range is unmapped later -- measured as 20-30 ms stalls of the
+// search that followed a file import.  `bytes` below kStagedCopyMin take the plain hipMemcpy.
+constexpr size_t kStagedCopyMin = 8u << 20;
+int staged_upload(void *dst_device, const void *src_host, size_t bytes);
+int staged_download(void *dst_host, const void *src_device, size_t bytes);
+
 // Owning device allocation. `front_pad` elements are kept in front of data() so that kernels
 // may read a little before the first element (diagonals that start left of the database).
 template <typename T> struct DevBuf {
@@ -105,6 +113,8 @@ template <typename T> struct DevBuf {
 			return fail(PGX_E_ARG, "upload larger than buffer");
 		if (count == 0)
 			return 0;
+		if (count * sizeof(T) >= kStagedCopyMin)
+			return staged_upload(data(), host, count * sizeof(T));
 		hipError_t e = hipMemcpy(data(), host, count * sizeof(T), hipMemcpyHostToDevice);
 		if (e != hipSuccess)
 			return fail(PGX_E_NODEVICE, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
@@ -114,6 +124,8 @@ template <typename T> struct DevBuf {
 	{
 		if (count == 0)
 			return 0;
+		if (count * sizeof(T) >= kStagedCopyMin)
+			return staged_download(host, data() + first, count * sizeof(T));
 		hipError_t e = hipMemcpy(host, data() + first, count * sizeof(T), hipMemcpyDeviceToHost);
 		if (e != hipSuccess)
 			return fail(PGX_E_NODEVICE, "hipMemcpy D2H failed: %s", hipGetErrorString(e));

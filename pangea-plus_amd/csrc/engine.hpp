@@ -71,6 +71,13 @@ struct pgx_db {
 	pgx::DevBuf<uint32_t> d_simrank_len;         // [length * 256 + mismatches] -> the same rank, alignments < 256 long
 	uint32_t simrank_undef = 0, simrank_zero = 0;
 	uint32_t intern(const std::string &s);
+	// text tables of the formatters in HBM, made at the first table that needs them and kept with the handle (they used to be
+	// put together and uploaded by every formatting call: 100 MB of lineage text per consensus file): subject ids, and the
+	// distinct lineage texts of the bound taxonomy (made again after a new binding)
+	mutable std::mutex fmt_mu;
+	mutable pgx::DevBuf<unsigned char> d_id_blob, d_lin_blob;
+	mutable pgx::DevBuf<uint32_t> d_id_off, d_lin_off;
+	mutable bool id_blob_ready = false, lin_blob_ready = false;
 };
 
 // A batch of reads in HBM: forward and reverse-complement strands, each read word-aligned.

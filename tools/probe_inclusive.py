@@ -20,4 +20,5 @@ for form in ("device", "device", "host", "device"):
     else:
         os.environ.pop("PGX_RDP_HOST", None)
     r = bench.inclusive(pg, _capi, cfg, db, tmp, 0, n)
-    print(form, json.dumps({"reads_per_s": round(r["value"]), **{k: round(v, 4) for k, v in r["stages_s"].items()}}), flush=True)
+    print(form, json.dumps({"reads_per_s": round(r["value"]), **{k: round(v, 4) for k, v in r["stages_s"].items()},
+                            "kernels_ms": round(r["classify_consensus_kernels_ms"], 1), "attempts": r["classify_consensus_attempts"]}), flush=True)
