@@ -32,6 +32,7 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 			     uint64_t piece, const std::function<int(const char *, size_t)> &sink, int *rc_out);
 bool consensus_format_device(const pgx_db *db, const pgx_reads *reads, const pgx_hits *hits, const pgx_consensus_rec *recs, int64_t n,
 			     std::string &out, int *rc_out);
+int formatter_tables(const pgx_db *db);
 void format_hit_columns(const pgx_hit &h, int64_t qlen, int64_t db_len, int64_t db_nseq, bool gapped, Text &out);
 
 // ------------------------------------------------------------------------------------------ lineage text
@@ -590,6 +591,7 @@ int pgx_db_bind_taxonomy(pgx_db *db, pgx_taxdb *tax)
 		PGX_TRY(db->d_subj_lin.upload(subj_lin.data(), n));
 	}
 	db->bound = true;
+	PGX_TRY(formatter_tables(db)); // the lineage texts in HBM, for the consensus text (blast_format.hip)
 	index_check(db, "bind_taxonomy");
 	return 0;
 }

@@ -345,6 +345,9 @@ static int text_table_once(const std::vector<std::string> &texts, std::mutex &mu
 	return 0;
 }
 
+// the lineage texts of a bound handle (pgx_db_bind_taxonomy calls this: binding is set-up, a consensus file is not)
+int formatter_tables(const pgx_db *db) { return text_table_once(db->lin_text, db->fmt_mu, db->lin_blob_ready, db->d_lin_blob, db->d_lin_off); }
+
 // renders the whole table; `sink` receives consecutive pieces of text
 int format_hits_stream(const pgx_hits *h, const pgx_db *db, const pgx_reads *reads,
 		       const std::function<int(const char *, size_t)> &sink)
@@ -628,15 +631,11 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 		c.recs = d_recs.data();
 		c.subj_lin = db->d_subj_lin.data();
 		const uint64_t N = (uint64_t)n, chunk = piece;
-		// two pinned buffers: the sink (a file writer) works on one piece while the next is rendered and copied
+		// two pinned buffers: the sink (a file writer) works on one piece while the next is rendered and copied.  They are
+		// the process's (pinning 90 MB costs as much as writing a piece): kept for the next table, one table at a time
 		struct Pinned {
 			char *p = nullptr;
 			size_t cap = 0;
-			~Pinned()
-			{
-				if (p)
-					(void)hipHostFree(p);
-			}
 			int ensure(size_t n)
 			{
 				if (n <= cap)
@@ -649,7 +648,10 @@ bool consensus_format_pieces(const pgx_db *db, const pgx_reads *reads, const pgx
 				cap = n + n / 8;
 				return 0;
 			}
-		} pin[2];
+		};
+		static std::mutex pin_mu;
+		static Pinned pin[2];
+		std::lock_guard<std::mutex> pin_lock(pin_mu);
 		std::future<int> pending; // the sink's call on the previous piece
 		uint64_t k_piece = 0;
 		DevBuf<unsigned long long> d_len, d_off;
