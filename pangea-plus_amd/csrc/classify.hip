@@ -1293,6 +1293,10 @@ __device__ __forceinline__ uint32_t pair_grid(const uint32_t (&pr)[15], const ui
 __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t subject, const uint32_t (&rc)[kRdpRegs],
 						  uint32_t r0, uint32_t r1, uint32_t *ntok_out)
 {
+#ifdef PGX_STAGE_PROBES
+	if (cv.dbg == 7)
+		subject &= 0x3FFFu; // (what the stage would cost if every subject's record were in L2: 16 384 records)
+#endif
 	const uint4 *rec = reinterpret_cast<const uint4 *>(cv.subj_pairs + (unsigned long long)cv.pair_words * subject);
 	const uint4 q0 = rec[0];
 	const uint32_t nt = q0.x & 0xFFFFu, np = q0.x >> 16;
@@ -1365,6 +1369,8 @@ struct SortWave {
 			uint32_t kcnt[kSortCap], sim_e[kSortCap], krm[kSortCap], rm[kSortCap], nxt[kSortCap];
 		} c;
 	};
+	uint32_t rcode[2][kRdpRegs]; // the RDP codes of the wave's (up to) two reads: fetched one per lane at the top of a round, read
+				     // back when the ranks are known -- eight registers per lane less through the ranking loops
 };
 
 // G lanes per read: G = 32 orders two reads per wavefront (most reads have <= 32 hits), G = 64 one.  A read with
@@ -1434,6 +1440,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		}
 		if (pass_on)
 			n = 0; // not ours
+		// the read's RDP codes (slots past the end match nothing): lane b of the read's lanes fetches code b
+		// (asked for before the rows: the two chains of dependent loads run side by side)
+		uint32_t rdp0 = 0, rdp1 = 0, my_code = 0xFFFFFFFEu;
+		bool present = true;
+		if (do_consensus && n) {
+			rdp0 = cv.rdp_off[r];
+			rdp1 = cv.rdp_off[r + 1];
+			if (li < kRdpRegs && rdp0 + (uint32_t)li < rdp1)
+				my_code = cv.rdp_code[rdp0 + (uint32_t)li];
+			if (cv.rdp_present)
+				present = cv.rdp_present[r] != 0;
+		}
 		// unfragmented reads still sit contiguously in the seed kernel's table; fragmented ones were scattered
 		uint32_t st0 = n ? read_start[r] : 0u;
 		if (n && st0 != kFragmented && (unsigned long long)st0 + n > scratch_cap) {
@@ -1450,19 +1468,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		// (rows past the read's end hold a subject no hit has, so the loops below need no "j < n" of their own)
 		sw->a.subj[slot0 + li] = mine ? h.subject : -1;
 		sw->a.score[slot0 + li] = h.score;
-		// the read's RDP codes (slots past the end match nothing)
-		uint32_t rcode[kRdpRegs], rdp0 = 0, rdp1 = 0;
-		if (do_consensus && n) {
-			rdp0 = cv.rdp_off[r];
-			rdp1 = cv.rdp_off[r + 1];
-#pragma unroll
-			for (int b = 0; b < kRdpRegs; b++)
-				rcode[b] = rdp0 + b < rdp1 ? cv.rdp_code[rdp0 + b] : 0xFFFFFFFEu;
-		} else {
-#pragma unroll
-			for (int b = 0; b < kRdpRegs; b++)
-				rcode[b] = 0xFFFFFFFEu;
-		}
+		if (li < kRdpRegs)
+			sw->rcode[g][li] = my_code;
 		lds_fence();
 		if (PGX_SORT_DBG(cv) == 1) {
 			if (mine)
@@ -1583,8 +1590,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 			continue;
 		uint32_t rmv = 0, ntok = 0, sim = 0;
 		if (kept) {
+			uint32_t rcode[kRdpRegs];
+#pragma unroll
+			for (int b = 0; b < kRdpRegs; b++)
+				rcode[b] = sw->rcode[g][b];
 			rmv = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
 			sim = hit_simrank(cv, h);
+		}
+		if (PGX_SORT_DBG(cv) == 5) { // (probe: the agreement counts alone)
+			if (__ballot(rmv + sim + ntok == 0xFFFFFFF0u) && li == 0)
+				recs[r].hit = 0;
+			continue;
 		}
 		// Consensus:186-204 is an order-dependent selection (ArgmaxState).  When every hit of the read has
 		// the same lineage token count c >= 1 -- the normal case -- it has a closed form: after the first
@@ -1597,7 +1613,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		const unsigned long long odd_mask = __ballot(odd);
 		const unsigned long long gmask = G == 64 ? ~0ull : (g ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
 		const bool slow = (odd_mask & gmask) != 0ull;
-		const bool present = !n || !cv.rdp_present || cv.rdp_present[r];
 		if (n && !present && li == 0) {
 			recs[r].hit = -2;
 			recs[r].matches = 0;
@@ -1608,6 +1623,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 		for (int m = 1; m < G; m <<= 1)
 			kmax = max(kmax, (uint32_t)__shfl_xor(kmax, m));
 		const bool elig = kept && k32 == kmax;
+		if (PGX_SORT_DBG(cv) == 6) { // (probe: + the first reduction)
+			if (__ballot(elig && slow && !present) && li == 0)
+				recs[r].hit = 0;
+			continue;
+		}
 		if (PGX_SORT_DBG(cv) != 4) {
 			const uint32_t key2 = elig ? ((sim << 6) | (63u - rank)) + 1u : 0u;
 			uint32_t top = key2;

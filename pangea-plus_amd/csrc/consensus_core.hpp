@@ -47,9 +47,11 @@ __device__ __forceinline__ uint64_t dec_str_key(uint32_t v)
 // the same order in 32 bits, for v < 10^8
 __device__ __forceinline__ uint32_t dec_str_key32(uint32_t v)
 {
-	const uint32_t p10[9] = { 1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u };
-	const int d = dec_digits(v);
-	return (v * p10[8 - d]) * 16u + (uint32_t)d;
+	// (selects, not a table of powers: the table is memory, and its load sat in the middle of the ordering kernel's chain)
+	const bool d1 = v < 10u, d2 = v < 100u, d3 = v < 1000u, d4 = v < 10000u, d5 = v < 100000u, d6 = v < 1000000u, d7 = v < 10000000u;
+	const uint32_t mul = d1 ? 10000000u : d2 ? 1000000u : d3 ? 100000u : d4 ? 10000u : d5 ? 1000u : d6 ? 100u : d7 ? 10u : 1u;
+	const uint32_t d = d1 ? 1u : d2 ? 2u : d3 ? 3u : d4 ? 4u : d5 ? 5u : d6 ? 6u : d7 ? 7u : 8u;
+	return (v * mul) * 16u + d;
 }
 
 // number of (a,b) with blasttax[a+1] eq clean(rdptax[b]) and index1 eq index2 (Consensus:154-184).

@@ -15,7 +15,7 @@ db.bind_taxonomy(tax)
 n = 10_000_000
 reads = pg.Reads.from_synth(cfg, 0, n)
 rdp = pg.Rdp.from_synth(cfg, 0, n, db)
-for stop in (1, 2, 3, 4, 0):
+for stop in (1, 2, 3, 5, 6, 4, 0, 7, 0):   # 7: every subject record read from an L2-resident part of the table (wrong answers, right cost)
     os.environ["PGX_SORT_STOP"] = str(stop)
     for it in range(2):
         _capi.classify_consensus(db, reads, rdp, want_records=False, want_hits=False)
