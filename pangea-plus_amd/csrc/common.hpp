@@ -57,7 +57,7 @@ template <typename F> int guard(const char *what, F &&body)
 // runtime a large PAGEABLE range (a file mapping, a vector, a numpy array) makes it pin those pages for the copy, and the
 // driver then stops every queue of the process when the range is unmapped later -- measured as 20-30 ms stalls of the
 // search that followed a file import.  `bytes` below kStagedCopyMin take the plain hipMemcpy.
-constexpr size_t kStagedCopyMin = 8u << 20;
+constexpr size_t kStagedCopyMin = 1u << 20;
 int staged_upload(void *dst_device, const void *src_host, size_t bytes);
 int staged_download(void *dst_host, const void *src_device, size_t bytes);
 
