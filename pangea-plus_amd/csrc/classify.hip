@@ -1,22 +1,31 @@
-// Classify kernels, BLAST mode (spec pgx-blastn v1) and the per-read consensus.
+// Classify kernels, BLAST mode (spec pgx-blastn v2): the seed + ungapped stage, the grouping of a search's
+// hits by read, and the per-read ordering + consensus.  The gapped stage between them is gapped.hip, query masking dust.hip.
 //
 // Replaces the arithmetic of `blastn -query F -db DB -outfmt 6` (reference README.md:96,
 // Scripts/run_multi_blastn.pl:56, Scripts/submit_MPI-blast.job:24) and the per-read arg-max of
 // Consensus/Consensus_BLAST_SOAP_RDP-1.1.pl:141-234.
 //
-// k_seed_extend   one wavefront per read.  Lanes first act as PROBES: the 16-mers at stride 13 of
-//                 both strands are looked up in the direct-address bucket table (one dependent
-//                 gather each).  The posting counts are prefix-summed across the wave and the
-//                 postings are then dealt to the 64 lanes as CANDIDATES, so a read with 3 or
-//                 3 000 postings keeps every lane busy.  A candidate lane builds the mismatch
-//                 words of its diagonal on demand (packed read XOR funnel-shifted database
-//                 window), rejects duplicates without any sort (only the left-most probe of the
-//                 first >=28 run of a diagonal reports it) and does the X-drop extension on the
-//                 bit masks.  Hits are staged in LDS per wave and appended to the global table
-//                 with one atomic per flush.
-// k_sort_consensus one wavefront per read: hits in LDS, rank sort into the -outfmt 6 order, then
-//                 (rank,name) agreement with the RDP assignment per hit and the order-dependent
-//                 arg-max with the Perl's string comparisons.
+// k_seed_extend<AMB, NW, LISTED, DUST>
+//                 one wavefront per TWO reads of up to NW x 64 bases (NW = 0: one read of any length).  Lanes first act as
+//                 PROBES: the 16-mers at stride 13 of both strands are looked up in the direct-address bucket table (one
+//                 dependent gather each).  The posting counts are prefix-summed across the wave and the postings -- 12-byte
+//                 records that carry the 13 database bases left and the 12 right of the 16-mer -- are dealt to the lanes
+//                 128 at a time: a posting whose flanks say the previous probe reports the same run, or that the exact run
+//                 is shorter than 28, is dropped before anything else is fetched.  Survivors get their block record
+//                 (subject, bounds), one candidate per (read, strand, diagonal) stays (an LDS set), and a queue hands 64
+//                 CANDIDATES at a time to the lanes: mismatch flags of the whole diagonal in registers (packed read XOR
+//                 funnel-shifted database window), DUST window bits (S3d), every exact run of >= 28, the X-drop walks of
+//                 the ungapped extension, and for the gapped stage the anchor and the level estimate B0.  Hits are staged
+//                 in LDS per read and leave contiguously into the wave's chunk of the table (one atomic per chunk).
+//                 search_pipeline (below) measures it stage by stage in PGX_STAGE_PROBES builds.
+// k_scan_*, k_scatter_hits, k_merge_pieces
+//                 per-read offsets of the table; only fragmented reads are moved.
+// k_sort_consensus<32 / 64>
+//                 one wavefront per two reads of up to 32 hits, then per read of 33-64: one hit per lane, keys in LDS, the
+//                 best score of a hit's subject, spec S3c (duplicate alignments of one subject), the rank by counting, the
+//                 ordered rows written out, then the (rank,name) agreement with the read's RDP assignment per hit and the
+//                 order-dependent arg-max of the Perl with its string comparisons as two reductions (a chain walk when
+//                 lineages differ in depth).  Reads with more hits: bigreads.hip.
 #include <algorithm>
 #include <chrono>
 

@@ -1,4 +1,5 @@
-// Status/error text, device selection, small host utilities.
+// Status/error text, device selection, small host utilities, and the ring of pinned buffers that large copies between host
+// memory and HBM go through (staged_upload / staged_download).
 #include <chrono>
 #include <cstring>
 #include <vector>

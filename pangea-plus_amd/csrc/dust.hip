@@ -8,21 +8,18 @@
 // The mask only removes SEEDS: what the seed stage reads is, per strand, one bit per read position i that says "the 28
 // bases from i on touch no masked base" (`d_dustwin_f`, `d_dustwin_r`; 64 positions per word at the read's word offset).
 //
-// k_dust_trigger<false>  one lane per read, linear: the published algorithm's own bookkeeping (window of the last 62
-//                 triplets with its pair count r_w; its longest suffix in which no triplet occurs more than 4 times, of L
-//                 triplets) and its test "10 r_w > 20 L", without which that algorithm never looks for a perfect interval
-//                 ending at the position.  93 % of random 150-base reads never pass it.  Triplets come from 64-bit
-//                 registers that move along the read; the suffix of ONE lane at a time is shrunk by the whole wavefront
-//                 (ballot for the earliest copy, a 64-bin histogram for the counters).
-// k_dust_trigger<true>   the listed reads again, packed: at every position that passes, the algorithm's walk over the
-//                 suffixes longer than that suffix; a read is kept when one scores above the level -- an interval above
-//                 the level exists exactly when a perfect one does (its best sub-interval), so these are the reads with a
-//                 masked base (the checker's fuzz of both tests against the definition: oracle/fuzz_dust.c) -- with the
-//                 first and last such position.
-// k_dust_mask     one lane per KEPT read: the definition itself, a dynamic programme over (first triplet a descending,
-//                 last triplet b ascending) restricted to intervals that end at or before the last such position and
-//                 start at most 61 triplets before the first; triplet counts and one row of best sub-interval scores in LDS
-// k_dust_windows  one lane per (read, 64 positions): the window bits of both strands from the mask
+// k_dust_scan<NW>   every read, one lane per read, linear: the published algorithm's own bookkeeping (the window of the last 62
+//                 triplets with its pair count r_w; L, the length of its longest suffix in which no triplet occurs more than
+//                 4 times) and its test "10 r_w > 20 L", without which that algorithm never looks for a perfect interval
+//                 ending at the position.  93 % of random 150-base reads never pass it.  The read sits in NW 64-bit
+//                 registers; the state is ONE LDS word per triplet value (window count + its last four positions), so the
+//                 suffix start moves with the entering triplet alone -- no walk.  Lists the reads with a position that
+//                 passes, with the first and last such position.
+// k_dust_perfect  ONE WAVEFRONT per listed read: the definition itself on the stretch the first pass marked, a dynamic
+//                 programme over the interval LENGTH with lane = interval start, neighbours by DPP wave shifts; writes the
+//                 masked bases and whether there are any (an interval above the level exists exactly when a perfect one
+//                 does; the checker's fuzz of the first pass's test against the definition: oracle/fuzz_dust.c).
+// k_dust_windows  one lane per (listed read with a masked base, 64 positions): the window bits of both strands from the mask
 #include <type_traits>
 
 #include "bitops.hpp"
@@ -31,32 +28,6 @@
 namespace pgx {
 
 constexpr int kDustMaxT = 62, kDustLevel = 20;
-
-struct DustLane {
-	uint8_t cnt[64];
-	uint32_t row[kDustMaxT + 2]; // score r | (triplets - 1) << 16; 0 = no score
-	uint32_t pad;                // 81 words per lane (odd stride: see TrigLane)
-};
-static_assert(sizeof(DustLane) / 4 % 2 == 1, "odd word stride");
-
-__device__ __forceinline__ bool frac_gt(uint32_t a, uint32_t b) // a > b; "no score" is below every score
-{
-	const uint32_t aq = a >> 16, bq = b >> 16;
-	if (aq == 0)
-		return false;
-	if (bq == 0)
-		return true;
-	return (a & 0xFFFFu) * bq > (b & 0xFFFFu) * aq;
-}
-
-// triplet value at position i of a packed read, or -1 (6 bits of the packed read; ambiguity flags of its three letters)
-__device__ __forceinline__ int dust_triplet(const uint64_t *rw, const uint64_t *ra, int i)
-{
-	const uint64_t w = window64(rw, i);
-	if (ra && (window64(ra, i) & 0x15ull))
-		return -1;
-	return (int)(((w & 3ull) << 4) | (((w >> 2) & 3ull) << 2) | ((w >> 4) & 3ull));
-}
 
 // LDS written by one lane, read by another of the same wavefront (LDS operations of a wavefront complete in order)
 __device__ __forceinline__ void dust_wave_sync()
