@@ -1306,8 +1306,11 @@ __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t su
 	if (cv.dbg == 7)
 		subject &= 0x3FFFu; // (what the stage would cost if every subject's record were in L2: 16 384 records)
 #endif
+	// (both halves of a 32-byte record are asked for at once: the second used to be asked for only after the first had
+	// arrived and said how many pairs there are -- two trips to memory in the middle of the ordering kernel's chain)
 	const uint4 *rec = reinterpret_cast<const uint4 *>(cv.subj_pairs + (unsigned long long)cv.pair_words * subject);
 	const uint4 q0 = rec[0];
+	const uint4 q1 = rec[1];
 	const uint32_t nt = q0.x & 0xFFFFu, np = q0.x >> 16;
 	*ntok_out = nt;
 	if (np == 0xFFFFu || r1 - r0 > (uint32_t)kRdpRegs) {
@@ -1316,7 +1319,6 @@ __device__ __forceinline__ uint32_t pair_matches(const ConsView &cv, uint32_t su
 		*ntok_out = n2;
 		return rank_matches(cv.subj_tok + t0, n2, cv.tok_rank, cv.rdp_name, cv.rdp_rank, r0, r1);
 	}
-	const uint4 q1 = rec[1];
 	uint4 q2 = make_uint4(0u, 0u, 0u, 0u), q3 = q2;
 	if (cv.pair_words > 8) { // (kernel-uniform: records of 32 bytes hold up to 7 pairs)
 		q2 = rec[2];
@@ -1603,8 +1605,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 8) void k_sort_consensus(pgx_h
 #pragma unroll
 			for (int b = 0; b < kRdpRegs; b++)
 				rcode[b] = sw->rcode[g][b];
+			sim = hit_simrank(cv, h); // (asked for first: its gather and the record's are in flight together)
 			rmv = pair_matches(cv, (uint32_t)h.subject, rcode, rdp0, rdp1, &ntok);
-			sim = hit_simrank(cv, h);
 		}
 		if (PGX_SORT_DBG(cv) == 5) { // (probe: the agreement counts alone)
 			if (__ballot(rmv + sim + ntok == 0xFFFFFFF0u) && li == 0)
