@@ -149,7 +149,7 @@ def test_soap_paired_end_equals_the_reference_binary(pg, gold, oracle_bin, tmp_p
     assert o.read_bytes() == oo.read_bytes() and u2.read_bytes() == ou2.read_bytes() and un.read_bytes() == oun.read_bytes()
 
 
-@pytest.mark.parametrize("seed", [11])
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("PGX_SOAP_PE_SEEDS", "11").split(",")])
 def test_soap_paired_end_seeded_pairs_match_oracle(pg, oracle_bin, tmp_path, seed):
     """Pairs cut from a repetitive synthetic reference (each sequence twice, the copy with a few substitutions: several valid
     pairs per read pair, levels 0-2 all in use), all three -r modes, through the executable: bytes of the checker."""
