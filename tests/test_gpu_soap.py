@@ -225,3 +225,28 @@ def test_soap_paired_end_refusals(pg, gold, tmp_path):
     with pytest.raises(_capi.PangeaError) as e:
         pg.soap(a, str(ref) + ".index", str(tmp_path / "o"), **{**kw, "b": str(short)})
     assert e.value.status == -7 and not os.path.exists(tmp_path / "o")
+
+
+def test_soap_paired_end_defaults_and_uneven_files(pg, gold, oracle_bin, tmp_path):
+    """-m / -x left out (soap's 400 / 600), -r 1 (one pair per read pair), no -u, and a B file that holds fewer reads than the
+    A file (the pairs are as many as the shorter file holds): bytes of the checker through the executable and the C ABI."""
+    g = os.path.join(gold, "soap")
+    ref = tmp_path / "ref.fa"
+    ref.write_bytes(open(os.path.join(g, "ref.fa"), "rb").read())
+    pg.soap_index(str(ref))
+    a = os.path.join(g, "pe_a.fa")
+    b_all = open(os.path.join(g, "pe_b.fa")).read().split(">")[1:]
+    b = tmp_path / "b.fa"
+    b.write_text("".join(">" + x for x in b_all[:150]))
+    p = subprocess.run([os.path.join(BIN, "soap"), "-a", a, "-b", str(b), "-D", str(ref) + ".index", "-o", str(tmp_path / "p.txt"), "-2",
+                        str(tmp_path / "p2.txt")])
+    assert p.returncode == 0 and not os.path.exists(tmp_path / "pu.txt")
+    assert run_cmd([oracle_bin, "soap", "-a", a, "-b", str(b), "-D", str(ref) + ".index", "-o", str(tmp_path / "o.txt"), "-2",
+                    str(tmp_path / "o2.txt")])[0] == 0
+    assert (tmp_path / "p.txt").read_bytes() == (tmp_path / "o.txt").read_bytes()
+    assert (tmp_path / "p2.txt").read_bytes() == (tmp_path / "o2.txt").read_bytes()
+    names = {l.split("\t")[0] for l in open(tmp_path / "p.txt")} | {l.split("\t")[0] for l in open(tmp_path / "p2.txt")}
+    assert max(int(n[1:].split("_")[0]) for n in names) == 149 and len(open(tmp_path / "p.txt").readlines()) > 100
+    # the same through the C ABI with min_insert = max_insert = 0 (the defaults)
+    pg.soap(a, str(ref) + ".index", str(tmp_path / "q.txt"), b=str(b), unpaired=str(tmp_path / "q2.txt"), m=0, x=0)
+    assert (tmp_path / "q.txt").read_bytes() == (tmp_path / "o.txt").read_bytes()
