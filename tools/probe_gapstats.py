@@ -12,7 +12,7 @@ from pangea_plus_amd import _capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 pg.init(0)
-cfg = pg.SynthCfg.default()
+cfg = pg.SynthCfg.default(read_len=int(os.environ.get("READ_LEN", "150")))  # READ_LEN=500: the deep rows
 tmp = tempfile.mkdtemp()
 _capi._check(pg.lib().pgx_synth_write_taxdump(C.byref(cfg), tmp.encode()))
 pg.TaxDb.create(tmp)
