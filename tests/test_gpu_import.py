@@ -120,3 +120,39 @@ def test_damaged_database_file_and_bad_rank_are_errors_not_crashes(tmp_path):
         with pytest.raises(_capi.PangeaError) as e:
             pg.blastn(str(q), str(tmp_path / "d"), str(tmp_path / "o.tsv"), rank=rk, world_size=ws)
         assert e.value.status == -1
+
+
+@pytest.mark.parametrize("target_bytes", [(1 << 20) - 4096, (1 << 20) + 4096, (8 << 20) + 17, 24 << 20, (70 << 20) + 12345])
+def test_fasta_text_sizes_around_the_copy_ring_stripes(target_bytes, tmp_path):
+    """Host copies of 1 MB and more go through the process's ring of pinned 8 MB buffers (common.hip: staged_upload /
+    staged_download): texts just below and above the threshold, one byte into a second stripe, whole stripes, and more
+    stripes than the ring has buffers (every worker reuses both of its buffers).  The batch must hold exactly the file's reads:
+    count, every length, and the letters of reads at the start, at every stripe boundary and at the end; the FASTA written
+    back from HBM must be the text that went in."""
+    import numpy as np
+    import pangea_plus_amd as pg
+    pg.init(0)
+    rng = np.random.default_rng(target_bytes)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs, size, i = [], 0, 0
+    while size < target_bytes:
+        L = int(rng.integers(60, 180))
+        rec = b">r%d\n" % i + letters[rng.integers(0, 4, L)].tobytes() + b"\n"
+        recs.append(rec)
+        size += len(rec)
+        i += 1
+    text = b"".join(recs)
+    reads = pg.Reads.from_fasta_text(text)
+    assert len(reads) == len(recs)
+    offs = np.cumsum([0] + [len(r) for r in recs])
+    picks = {0, 1, len(recs) - 1, len(recs) - 2}
+    for edge in range(8 << 20, len(text), 8 << 20):      # the reads that straddle a stripe boundary, and their neighbours
+        k = int(np.searchsorted(offs, edge)) - 1
+        picks |= {max(k - 1, 0), k, min(k + 1, len(recs) - 1)}
+    for k in sorted(picks):
+        want = recs[k].split(b"\n")[1]
+        got = bytes(b"ACGTN"[c] for c in reads.get(k))
+        assert got == want, k
+    out = tmp_path / "back.fa"
+    reads.write_fasta(str(out))
+    assert out.read_bytes() == text
